@@ -1,0 +1,45 @@
+# make            -> libwinograd_mi355x.so + ./Test (the reference's `make && ./Test 0` UX)
+# make oracle     -> oracle/liboracle.so (CPU checker, test infrastructure only)
+# hipcc cross-compiles for gfx950 without a GPU.
+HIPCC   ?= hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+PKG     := cuda-winograd_amd
+CSRC    := $(PKG)/csrc
+HOST    := $(PKG)/host
+BUILD   := build
+
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+CFLAGS   := -O2 -fPIC -std=gnu11 -Iinclude -Wall
+
+HIP_SRCS := $(wildcard $(CSRC)/*.hip)
+HIP_OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIP_SRCS))
+HOST_OBJS := $(BUILD)/util.o $(BUILD)/layer_driver.o
+
+LIB := $(PKG)/libwinograd_mi355x.so
+
+all: $(LIB) Test
+
+$(BUILD):
+	mkdir -p $(BUILD)
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/wino_common.h include/winograd_mi355x.h | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(BUILD)/%.o: $(HOST)/%.c include/winograd_mi355x.h include/util.h | $(BUILD)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIB): $(HIP_OBJS) $(HOST_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -lm
+
+Test: $(BUILD)/Test.o $(LIB)
+	$(CC) -o $@ $(BUILD)/Test.o -L$(PKG) -lwinograd_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -lpthread -lm
+
+oracle: oracle/liboracle.so
+oracle/liboracle.so: oracle/cpu_conv.c
+	$(CC) -O3 -march=x86-64-v3 -fPIC -shared -std=gnu11 -o $@ $< -lpthread -lm
+
+clean:
+	rm -rf $(BUILD) $(LIB) Test oracle/liboracle.so
+
+.PHONY: all oracle clean

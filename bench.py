@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: fused Winograd 3x3 conv + BN + ReLU, 256->256, 14x14, N=128.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--layer NAME] [--no-cpu-baseline]
+
+One "step" = one pass of the hot path (ONE launch of the fused HIP kernel through the
+C-ABI) over one batch of synthetic input that is already resident in HBM.  With N GPUs the
+batch is split by image: every rank owns a full N=128 batch (weak scaling, global batch
+128*N), weights replicated, NO collective on the data path; RCCL is used only for the
+barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0).  `value` = algorithmic FLOPs of all ranks / wall time, where
+algorithmic FLOPs are the direct-convolution FLOPs 2*N*P*Q*K*C*R*S, so
+it may exceed the fp32 MFMA peak: F(2x2,3x3) executes 2.25x fewer multiplies.  `roofline`
+carries both the effective fraction and the executed-MFMA fraction.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+
+# (kind, C_in, K_out, relu) of the reference's six layers; N = 128 per GPU
+LAYERS = {
+    "conv3x3_256": ("3x3", 256, 256, True),    # BASELINE configs[2] -- the headline
+    "conv3x3_128": ("3x3", 128, 128, True),    # configs[1]
+    "conv1x1_512_128": ("1x1", 512, 128, True),
+    "conv1x1_128_512": ("1x1", 128, 512, False),
+    "conv1x1_1024_256": ("1x1", 1024, 256, True),
+    "conv1x1_256_1024": ("1x1", 256, 1024, False),
+}
+BATCH = 128
+
+
+def algorithmic_flops(kind: str, N: int, C: int, K: int) -> float:
+    return 2.0 * N * 14 * 14 * K * C * (9 if kind == "3x3" else 1)
+
+
+def executed_mfma_flops(kind: str, N: int, C: int, K: int) -> float:
+    """FLOPs the MFMA pipes execute: F(2x2,3x3) = 16 points x (N*49 tiles) x C x K x 2."""
+    return 2.0 * 16 * N * 49 * C * K if kind == "3x3" else algorithmic_flops(kind, N, C, K)
+
+
+# ------------------------------------------------------------------ distributed plumbing
+def dist_env():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def dist_init(backend: str):
+    """One process per GPU; the process group exists only for barrier + max(time)."""
+    import torch.distributed as dist
+    rank, local_rank, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def timed_steps(step_fn, steps: int, warmup: int, sync_fn, barrier_fn) -> float:
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + sync on both
+    sides.  Returns this rank's elapsed seconds."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    t1 = time.perf_counter()
+    return t1 - t0
+
+
+def max_over_ranks(seconds: float, world: int, device=None) -> float:
+    if world == 1:
+        return seconds
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ------------------------------------------------------------------ CPU baseline (rank 0, N=1 GPU)
+def cpu_baseline(kind, C, K, relu, images: int):
+    """The oracle's naive C im2col + triple-loop SGEMM (+BN+ReLU), pthreads over output rows,
+    timed on this box's host cores on a bounded sample of the same workload."""
+    import numpy as np
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "oracle"], cwd=ROOT, stdout=subprocess.DEVNULL)
+    L = ctypes.CDLL(path)
+    vp = ctypes.c_void_p
+    L.oracle_conv3x3_im2col.argtypes = [vp, vp, vp, vp, vp] + [ctypes.c_int] * 5
+    L.oracle_conv1x1.argtypes = [vp, vp, vp, vp, vp, ctypes.c_long] + [ctypes.c_int] * 4
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    rng = np.random.RandomState(0)
+    p = lambda a: a.ctypes.data_as(vp)
+    s = (rng.rand(K) - 0.5).astype(np.float32)
+    b = (rng.rand(K) - 0.5).astype(np.float32)
+    if kind == "3x3":
+        x = (rng.rand(images, 16, 16, C) - 0.5).astype(np.float32)
+        w = (rng.rand(K, C, 3, 3) - 0.5).astype(np.float32)
+        out = np.empty((images, 16, 16, K), np.float32)
+        run = lambda: L.oracle_conv3x3_im2col(p(x), p(w), p(s), p(b), p(out), images, C, K, int(relu), cores)
+    else:
+        M = images * 196
+        A = ((rng.rand(M, C) - 0.5) * 40).astype(np.float32)
+        B = ((rng.rand(C, K) - 0.5) * 40).astype(np.float32)
+        out = np.empty((M, K), np.float32)
+        run = lambda: L.oracle_conv1x1(p(A), p(B), p(b), p(s), p(out), M, C, K, int(relu), cores)
+    run()  # warm-up (page faults, thread start)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 3.0 or reps >= 5:
+            break
+    sec = dt / reps
+    return {"value": algorithmic_flops(kind, images, C, K) / sec / 1e12, "unit": "TFLOP/s",
+            "cores": cores, "kind": "port",
+            "sample": f"{images} of {BATCH} images of the same layer, naive C im2col+SGEMM+BN+ReLU "
+                      f"(oracle/cpu_conv.c), {reps} reps, {sec * 1e3:.1f} ms each",
+            "us_per_layer_extrapolated": sec * 1e6 * BATCH / images}
+
+
+def pmc_traffic(layer: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(layer, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+# ------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--layer", default="conv3x3_256", choices=sorted(LAYERS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=16)
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # convenience: relaunch under torch.distributed.run as a CHILD (never exec after GPU init)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", "29513",
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+
+    pkg = ge.load_package()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    rank, local_rank, world = dist_init("nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    kind, C, K, relu = LAYERS[args.layer]
+    N = BATCH
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    rnd = lambda *shape, scale=1.0: ((torch.rand(*shape, generator=g) - 0.5) * scale).to(dev)
+    scale_v, bias_v = rnd(K), rnd(K)
+    if kind == "3x3":
+        x = rnd(N, 16, 16, C)
+        U = pkg.filter_transform_f2(rnd(K, C, 3, 3))       # offline, outside the timed region
+        out = torch.empty((N, 16, 16, K), device=dev)
+        step = lambda: pkg.conv3x3_bn_relu(x, U, bias_v, scale_v, relu=relu, out=out)
+    else:
+        A = rnd(N * 196, C, scale=40.0)
+        B = rnd(C, K, scale=40.0)
+        out = torch.empty((N * 196, K), device=dev)
+        step = lambda: pkg.conv1x1_bn(A, B, bias_v, scale_v, relu, out=out)
+
+    sync = lambda: torch.cuda.synchronize(dev)
+    if world > 1:
+        import torch.distributed as dist
+        barrier = lambda: dist.barrier(device_ids=[local_rank])
+    else:
+        barrier = lambda: None
+
+    # kernel time by HIP events on the launch stream (the ops launch on torch's current stream)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    state = {"n": 0}
+
+    def step_with_events():
+        if state["n"] == 0:
+            ev0.record()
+        step()
+        state["n"] += 1
+        if state["n"] == args.steps:
+            ev1.record()
+
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed_steps(step_with_events, args.steps, 0, sync, barrier)
+    elapsed = max_over_ranks(elapsed, world, dev)
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+
+    flops_rank = algorithmic_flops(kind, N, C, K)
+    value = flops_rank * world * args.steps / elapsed / 1e12
+    ach = flops_rank / (kernel_ms * 1e-3) / 1e12
+    line = {
+        "metric": f"effective_tflops_{args.layer}_bn_relu_14x14_N128_fp32" if kind == "3x3"
+                  else f"effective_tflops_{args.layer}_bn_14x14_N128_fp32",
+        "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "us_per_layer": round(elapsed / args.steps * 1e6, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{kind} conv {C}->{K} + folded BN" + (" + ReLU" if relu else "") +
+                               f", 14x14 (16x16 padded NHWC), N={N} per GPU, fp32",
+                   "algorithm": "fused Winograd F(2x2,3x3), one HIP launch" if kind == "3x3"
+                                else "fp32 MFMA GEMM, one HIP launch",
+                   "global_batch": N * world, "parallelism": f"batch-split x{world}, no collective"},
+        "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                     "traffic": pmc_traffic(args.layer),
+                     "kernel_us": round(kernel_ms * 1e3, 2),
+                     "executed_mfma_frac": round(executed_mfma_flops(kind, N, C, K) /
+                                                 (kernel_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                     "note": "achieved = algorithmic (direct-conv) FLOPs per launch / mean launch "
+                             "duration from HIP events; Winograd executes 2.25x fewer MFMA FLOPs"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(kind, C, K, relu, args.cpu_images)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,200 @@
+"""cuda-winograd_amd -- MI355X-native fused Winograd conv(+BN+ReLU) and 1x1-conv GEMM.
+
+Python side of the drop-in boundary: a ctypes binding of the C-ABI declared in
+``include/winograd_mi355x.h`` (the same shared library the C ``./Test`` driver
+links), plus thin operator wrappers that take torch tensors.  PyTorch is only
+plumbing here (device memory, streams, ``torch.distributed``); every compute
+call goes to the hand-written HIP kernels in ``csrc/``.  There is NO CPU or
+eager fallback: if the library is missing or no GPU is visible, calls raise.
+
+The directory name contains a hyphen, so import it through
+``__graft_entry__.load_package()`` (registers it as ``cuda_winograd_amd``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_long, c_size_t, c_void_p, POINTER
+
+import torch  # imported first on purpose: the library then binds to torch's HIP runtime
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwinograd_mi355x.so")
+
+# every symbol include/*.h declares (tests/test_abi.py checks the export table against it)
+ABI_SYMBOLS = [
+    "wino_abi_version", "wino_last_error_string", "wino_device_count", "wino_set_device",
+    "wino_device_name", "wino_malloc", "wino_free", "wino_memset", "wino_memcpy_h2d",
+    "wino_memcpy_d2h", "wino_memcpy_d2d", "wino_device_synchronize", "wino_stream_create",
+    "wino_stream_destroy", "wino_stream_synchronize", "wino_event_create", "wino_event_destroy",
+    "wino_event_record", "wino_event_elapsed_ms", "wino_filter_f2_elems",
+    "wino_filter_transform_f2", "wino_filter_import_f4", "wino_conv3x3_bn_relu",
+    "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_direct", "wino_driver_set_batch",
+    "wino_driver_set_gpus", "wino_driver_set_quiet", "wino_driver_get_batch",
+    "wino_driver_get_gpus", "wino_driver_last_result",
+    # reference entry points + helpers (Kernel*.h, util.h)
+    "kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in",
+    "kernel_256_1_out", "get_parameter", "transpose", "getTimeMicroseconds64", "output_checker",
+    "output_checker_accumulate",
+]
+
+
+class WinoError(RuntimeError):
+    pass
+
+
+class DriverResult(ctypes.Structure):
+    _fields_ = [("mine_us", ctypes.c_double), ("comparator_us", ctypes.c_double),
+                ("max_abs_err", ctypes.c_double), ("max_rel_err", ctypes.c_double),
+                ("error_cnt", c_long), ("flops", ctypes.c_double), ("N", c_int), ("gpus", c_int)]
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libwinograd_mi355x.so (built in-tree by `make` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WinoError(
+            f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()). "
+            "There is no fallback path.")
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    fp = c_void_p
+    L.wino_last_error_string.restype = c_char_p
+    L.wino_filter_f2_elems.restype = c_size_t
+    L.wino_filter_f2_elems.argtypes = [c_int, c_int]
+    L.wino_filter_transform_f2.argtypes = [fp, fp, c_int, c_int, c_void_p]
+    L.wino_filter_import_f4.argtypes = [fp, fp, c_int, c_int, c_void_p]
+    L.wino_conv3x3_bn_relu.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_void_p]
+    L.wino_conv3x3_direct.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_void_p]
+    L.wino_conv1x1_bn.argtypes = [fp, fp, fp, fp, fp, c_long, c_int, c_int, c_int, c_void_p]
+    L.wino_conv1x1_direct.argtypes = [fp, fp, fp, fp, fp, c_long, c_int, c_int, c_int, c_void_p]
+    L.wino_device_count.argtypes = [POINTER(c_int)]
+    L.wino_driver_last_result.argtypes = [POINTER(DriverResult)]
+    L.wino_driver_set_batch.argtypes = [c_int]
+    L.wino_driver_set_gpus.argtypes = [c_int]
+    L.wino_driver_set_quiet.argtypes = [c_int]
+    for name in ("kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out",
+                 "kernel_256_1_in", "kernel_256_1_out"):
+        getattr(L, name).restype = c_int
+        getattr(L, name).argtypes = []
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise WinoError(f"{what} failed (rc={rc}): {lib().wino_last_error_string().decode()}")
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise WinoError(f"{name} must be a CUDA(HIP) tensor -- this framework has no CPU path")
+    if t.dtype != torch.float32:
+        raise WinoError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# --------------------------------------------------------------------------- operators
+def filter_transform_f2(w_kcrs: torch.Tensor) -> torch.Tensor:
+    """[K][C][3][3] taps -> packed F(2x2,3x3) filter buffer (opaque layout, 16*C*K floats)."""
+    w = _dev(w_kcrs, "w_kcrs")
+    K, C = int(w.shape[0]), int(w.shape[1])
+    if tuple(w.shape[2:]) != (3, 3):
+        raise WinoError("w_kcrs must be [K][C][3][3]")
+    U = torch.empty(lib().wino_filter_f2_elems(C, K), dtype=torch.float32, device=w.device)
+    _check(lib().wino_filter_transform_f2(w.data_ptr(), U.data_ptr(), C, K, _stream()),
+           "wino_filter_transform_f2")
+    return U
+
+
+def filter_import_f4(u36: torch.Tensor) -> torch.Tensor:
+    """The reference's weight_winograd_C_K.bin tensor [36][C][K] -> packed F(2x2) buffer."""
+    u = _dev(u36, "u36")
+    if u.dim() != 3 or u.shape[0] != 36:
+        raise WinoError("u36 must be [36][C][K]")
+    C, K = int(u.shape[1]), int(u.shape[2])
+    U = torch.empty(lib().wino_filter_f2_elems(C, K), dtype=torch.float32, device=u.device)
+    _check(lib().wino_filter_import_f4(u.data_ptr(), U.data_ptr(), C, K, _stream()),
+           "wino_filter_import_f4")
+    return U
+
+
+def conv3x3_bn_relu(inp: torch.Tensor, U: torch.Tensor, bn_bias: torch.Tensor,
+                    bn_scale: torch.Tensor, relu: bool = True,
+                    out: torch.Tensor | None = None) -> torch.Tensor:
+    """inp [N][16][16][C] -> out [N][16][16][K] (interior 14x14, zero ring).  One HIP launch."""
+    x = _dev(inp, "inp")
+    U = _dev(U, "U")
+    b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
+    if x.dim() != 4 or x.shape[1] != 16 or x.shape[2] != 16:
+        raise WinoError("inp must be [N][16][16][C]")
+    N, C, K = int(x.shape[0]), int(x.shape[3]), int(b.numel())
+    if U.numel() != 16 * C * K or s.numel() != K:
+        raise WinoError("U / bn vectors do not match C, K")
+    if out is None:
+        out = torch.empty((N, 16, 16, K), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (N, 16, 16, K) or not out.is_contiguous():
+        raise WinoError("out must be a contiguous [N][16][16][K] tensor")
+    _check(lib().wino_conv3x3_bn_relu(x.data_ptr(), U.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                      out.data_ptr(), N, C, K, int(relu), _stream()),
+           "wino_conv3x3_bn_relu")
+    return out
+
+
+def conv3x3_direct(inp, w_kcrs, bn_bias, bn_scale, relu: bool = True) -> torch.Tensor:
+    """Comparator: direct 3x3 conv + BN + ReLU on the GPU (not the product path)."""
+    x, w = _dev(inp, "inp"), _dev(w_kcrs, "w_kcrs")
+    b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
+    N, C, K = int(x.shape[0]), int(x.shape[3]), int(w.shape[0])
+    out = torch.empty((N, 16, 16, K), dtype=torch.float32, device=x.device)
+    _check(lib().wino_conv3x3_direct(x.data_ptr(), w.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                     out.data_ptr(), N, C, K, int(relu), _stream()),
+           "wino_conv3x3_direct")
+    return out
+
+
+def conv1x1_bn(A: torch.Tensor, B: torch.Tensor, bn_bias: torch.Tensor, bn_scale: torch.Tensor,
+               relu: bool, out: torch.Tensor | None = None) -> torch.Tensor:
+    """A [M][Cin] @ B [Cin][Kout] -> scale*(.)+bias (+ReLU), [M][Kout].  One HIP launch."""
+    a, bm = _dev(A, "A"), _dev(B, "B")
+    b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
+    if a.dim() != 2 or bm.dim() != 2 or a.shape[1] != bm.shape[0]:
+        raise WinoError("A must be [M][Cin], B [Cin][Kout]")
+    M, Cin, Kout = int(a.shape[0]), int(a.shape[1]), int(bm.shape[1])
+    if b.numel() != Kout or s.numel() != Kout:
+        raise WinoError("bn vectors do not match Kout")
+    if out is None:
+        out = torch.empty((M, Kout), dtype=torch.float32, device=a.device)
+    _check(lib().wino_conv1x1_bn(a.data_ptr(), bm.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                 out.data_ptr(), M, Cin, Kout, int(relu), _stream()),
+           "wino_conv1x1_bn")
+    return out
+
+
+def conv1x1_direct(A, B, bn_bias, bn_scale, relu: bool) -> torch.Tensor:
+    a, bm = _dev(A, "A"), _dev(B, "B")
+    b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
+    M, Cin, Kout = int(a.shape[0]), int(a.shape[1]), int(bm.shape[1])
+    out = torch.empty((M, Kout), dtype=torch.float32, device=a.device)
+    _check(lib().wino_conv1x1_direct(a.data_ptr(), bm.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                     out.data_ptr(), M, Cin, Kout, int(relu), _stream()),
+           "wino_conv1x1_direct")
+    return out
+
+
+# ---------------------------------------------------------------- batch split (multi-GPU)
+def shard_range(N: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous image range [n0, n1) of `rank` when N images are split over `world` GPUs.
+    The path has no exchange step: every image is independent, weights are replicated, so
+    there is no collective on the data path."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return (N * rank) // world, (N * (rank + 1)) // world

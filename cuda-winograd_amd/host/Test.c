@@ -1,0 +1,79 @@
+/*
+ * Test.c -- the ./Test <mode 0..5> command-line driver.
+ *
+ * Same protocol as the reference's Test.c:13-56: select device 0, run the chosen layer
+ * entry point 100 times, print "---- Iter: i ----" before each call, discard the first
+ * two results, average the two packed 16-bit timers over the remaining 98.
+ *
+ *   ./Test [mode] [N] [gpus] [iters]
+ *     mode   0 kernel_128   1 kernel_256   2 kernel_128_1_in   3 kernel_128_1_out
+ *            4 kernel_256_1_in   5 kernel_256_1_out            (default 0)
+ *     N      batch size (default 1 = the reference)            [extension]
+ *     gpus   devices to split N over, no collective (default 1) [extension]
+ *     iters  number of calls (default 100)                      [extension]
+ *
+ * After the reference's "Average Total Time" line a one-line JSON summary carries the
+ * unclamped averages, effective TFLOP/s on the algorithmic (direct-convolution) FLOPs,
+ * its fraction of the 157.3 TFLOP/s fp32 MFMA peak of one MI355X, and the error metrics.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "Kernel128_one.h"
+#include "Kernel128_winograd.h"
+#include "Kernel256_one.h"
+#include "Kernel256_winograd.h"
+#include "winograd_mi355x.h"
+
+#define MI355X_FP32_MFMA_PEAK_TFLOPS 157.3
+
+typedef int (*layer_fn)(void);
+static const struct { const char* name; layer_fn fn; } LAYERS[6] = {
+    {"kernel_128", kernel_128},           {"kernel_256", kernel_256},
+    {"kernel_128_1_in", kernel_128_1_in}, {"kernel_128_1_out", kernel_128_1_out},
+    {"kernel_256_1_in", kernel_256_1_in}, {"kernel_256_1_out", kernel_256_1_out}};
+
+int main(int argc, char** argv) {
+  int mode = argc > 1 ? atoi(argv[1]) : 0;
+  if (argc > 2) wino_driver_set_batch(atoi(argv[2]));
+  if (argc > 3) wino_driver_set_gpus(atoi(argv[3]));
+  int nTest = argc > 4 ? atoi(argv[4]) : 100;
+  if (nTest < 3) nTest = 3;
+  if (mode < 0 || mode > 5) mode = 0;
+
+  if (wino_set_device(0) != WINO_OK) {
+    printf("HIP failure: %s\n", wino_last_error_string());
+    return EXIT_FAILURE;
+  }
+
+  long sum_mine = 0, sum_cmp = 0;
+  double us_mine = 0, us_cmp = 0, worst_abs = 0, worst_rel = 0;
+  long worst_cnt = 0;
+  wino_driver_result r;
+  for (int i = 0; i < nTest; ++i) {
+    printf("---- Iter: %d ----\n", i);
+    const int packed = LAYERS[mode].fn();
+    wino_driver_last_result(&r);
+    if (r.max_abs_err > worst_abs) worst_abs = r.max_abs_err;
+    if (r.max_rel_err > worst_rel) worst_rel = r.max_rel_err;
+    if (r.error_cnt > worst_cnt) worst_cnt = r.error_cnt;
+    if (i > 1) { /* first two calls are warm-up (Test.c:45-48) */
+      sum_mine += packed >> 16;
+      sum_cmp += packed & 0xFFFF;
+      us_mine += r.mine_us;
+      us_cmp += r.comparator_us;
+    }
+  }
+  const int counted = nTest - 2;
+  printf("Average Total Time: [Mine: %d us], [Direct: %d us]\n", (int)(sum_mine / counted),
+         (int)(sum_cmp / counted));
+  us_mine /= counted;
+  us_cmp /= counted;
+  const double tflops = r.flops / (us_mine * 1e-6) / 1e12;
+  printf("{\"layer\": \"%s\", \"N\": %d, \"gpus\": %d, \"iters\": %d, \"mine_us\": %.1f, "
+         "\"comparator_us\": %.1f, \"effective_tflops\": %.3f, \"frac_of_fp32_mfma_peak\": %.4f, "
+         "\"max_abs_err\": %.6g, \"max_rel_err\": %.3g, \"error_cnt_1e-5\": %ld}\n",
+         LAYERS[mode].name, r.N, r.gpus, nTest, us_mine, us_cmp, tflops,
+         tflops / (MI355X_FP32_MFMA_PEAK_TFLOPS * r.gpus), worst_abs, worst_rel, worst_cnt);
+  return 0;
+}

@@ -1,0 +1,302 @@
+/*
+ * layer_driver.c -- the six argument-less reference entry points, host side in C.
+ *
+ * Mirrors the host drivers of the reference (Kernel128_winograd.cu:215-434,
+ * Kernel256_winograd.cu:220-429, Kernel128_one.cu:57-240,276-447,
+ * Kernel256_one.cu:59-242,277-449): load the .bin files, upload, time
+ * launch..synchronise with the wall clock, copy back, run a comparator on the same data,
+ * diff with output_checker, return (mine_us << 16) | comparator_us.
+ *
+ * Differences, all additive:
+ *   - the GPU work goes through the C-ABI of winograd_mi355x.h (no HIP headers here);
+ *   - the comparator is this library's direct-convolution kernel, not cuDNN;
+ *   - batch N and GPU count come from wino_driver_set_batch/_gpus (default 1/1 = the
+ *     reference).  With G GPUs the batch is split contiguously, weights are replicated,
+ *     one host thread drives each device and there is no inter-GPU communication; the
+ *     reported time is (last finish - common start) over all devices;
+ *   - both timers are clamped to 16 bits in the packed return value; exact numbers are
+ *     available from wino_driver_last_result().
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "Kernel128_one.h"
+#include "Kernel128_winograd.h"
+#include "Kernel256_one.h"
+#include "Kernel256_winograd.h"
+#include "util.h"
+#include "winograd_mi355x.h"
+
+#define HW WINO_HW
+#define PQ WINO_PQ
+#define MAX_GPUS 64
+
+/* ---------------------------------------------------------------- configuration */
+static int g_batch = 0, g_gpus = 0, g_quiet = -1;
+static wino_driver_result g_last;
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+int wino_driver_get_batch(void) {
+  if (g_batch <= 0) g_batch = env_int("WINO_BATCH", 1);
+  if (g_batch <= 0) g_batch = 1;
+  return g_batch;
+}
+int wino_driver_get_gpus(void) {
+  if (g_gpus <= 0) g_gpus = env_int("WINO_GPUS", 1);
+  if (g_gpus <= 0) g_gpus = 1;
+  if (g_gpus > MAX_GPUS) g_gpus = MAX_GPUS;
+  return g_gpus;
+}
+static int quiet(void) {
+  if (g_quiet < 0) g_quiet = env_int("WINO_QUIET", 0);
+  return g_quiet;
+}
+int wino_driver_set_batch(int N) { if (N < 1) return WINO_E_ARG; g_batch = N; return WINO_OK; }
+int wino_driver_set_gpus(int n) { if (n < 1 || n > MAX_GPUS) return WINO_E_ARG; g_gpus = n; return WINO_OK; }
+int wino_driver_set_quiet(int q) { g_quiet = q ? 1 : 0; return WINO_OK; }
+int wino_driver_last_result(wino_driver_result* r) { if (!r) return WINO_E_ARG; *r = g_last; return WINO_OK; }
+
+/* ---------------------------------------------------------------- small helpers */
+static void die_on(int rc, const char* what) {
+  if (rc != WINO_OK) {
+    /* the reference's cudaCheckError exits with EXIT_FAILURE (Kernel128_winograd.cu:16-22) */
+    printf("HIP failure in %s: %s\n", what, wino_last_error_string());
+    exit(EXIT_FAILURE);
+  }
+}
+#define CK(call) die_on((call), #call)
+
+static int file_exists(const char* p) {
+  FILE* f = fopen(p, "rb");
+  if (!f) return 0;
+  fclose(f);
+  return 1;
+}
+
+/* N activations from the reference's single-image file: image 0 is the file itself; image n
+ * is the file with its channel index rotated by n (deterministic, full-range, no zeros).
+ * A generator-written batched file is used instead when present. */
+static float* load_batched(const char* single, const char* batched_fmt_name, int per_image,
+                           int channels, int N) {
+  if (N == 1) return get_parameter(single, per_image);
+  if (batched_fmt_name && file_exists(batched_fmt_name)) return get_parameter(batched_fmt_name, per_image * N);
+  float* one = get_parameter(single, per_image);
+  float* all = (float*)malloc((size_t)per_image * N * sizeof(float));
+  if (!all) { printf("Bad Malloc\n"); exit(0); }
+  const int pixels = per_image / channels;
+  for (int n = 0; n < N; ++n)
+    for (int p = 0; p < pixels; ++p) {
+      const float* s = one + (size_t)p * channels;
+      float* d = all + ((size_t)n * pixels + p) * channels;
+      const int rot = n % channels;
+      memcpy(d, s + rot, (size_t)(channels - rot) * sizeof(float));
+      memcpy(d + channels - rot, s, (size_t)rot * sizeof(float));
+    }
+  free(one);
+  return all;
+}
+
+/* ---------------------------------------------------------------- per-device job */
+typedef struct {
+  int device, kind;           /* kind 3 = 3x3 winograd layer, 1 = 1x1 layer */
+  int n0, n;                  /* image range on this device */
+  int C, K, relu;
+  const float *h_in, *h_w_wino, *h_w_cmp, *h_bias, *h_scale;
+  float *h_out, *h_cmp;       /* this device's slices of the host outputs */
+  pthread_barrier_t* bar;
+  uint64_t t0_mine, t1_mine, t0_cmp, t1_cmp;
+} job_t;
+
+static void* job_main(void* arg) {
+  job_t* j = (job_t*)arg;
+  const int C = j->C, K = j->K, n = j->n;
+  CK(wino_set_device(j->device));
+  float *d_in, *d_out, *d_bias, *d_scale, *d_w, *d_U = NULL, *d_cmp;
+  const size_t in_elems = j->kind == 3 ? (size_t)n * HW * HW * C : (size_t)n * PQ * PQ * C;
+  const size_t out_elems = j->kind == 3 ? (size_t)n * HW * HW * K : (size_t)n * PQ * PQ * K;
+  const size_t w_elems = j->kind == 3 ? (size_t)36 * C * K : (size_t)C * K;
+  const size_t wc_elems = j->kind == 3 ? (size_t)9 * C * K : (size_t)C * K;
+
+  /* 1. data preparation (outside the timed region, as in the reference) */
+  CK(wino_malloc((void**)&d_in, in_elems * 4));
+  CK(wino_malloc((void**)&d_out, out_elems * 4));
+  CK(wino_malloc((void**)&d_cmp, out_elems * 4));
+  CK(wino_malloc((void**)&d_bias, (size_t)K * 4));
+  CK(wino_malloc((void**)&d_scale, (size_t)K * 4));
+  CK(wino_malloc((void**)&d_w, (w_elems > wc_elems ? w_elems : wc_elems) * 4));
+  CK(wino_memset(d_out, 0xff, out_elems * 4)); /* poison: every element must be written */
+  CK(wino_memcpy_h2d(d_in, j->h_in, in_elems * 4));
+  CK(wino_memcpy_h2d(d_bias, j->h_bias, (size_t)K * 4));
+  CK(wino_memcpy_h2d(d_scale, j->h_scale, (size_t)K * 4));
+  CK(wino_memcpy_h2d(d_w, j->h_w_wino, w_elems * 4));
+  if (j->kind == 3) {
+    CK(wino_malloc((void**)&d_U, wino_filter_f2_elems(C, K) * 4));
+    CK(wino_filter_import_f4(d_w, d_U, C, K, NULL)); /* offline weight transform */
+  }
+  CK(wino_device_synchronize());
+
+  /* 2. computing: wall clock around launch .. device sync (Kernel128_winograd.cu:261-269) */
+  if (j->bar) pthread_barrier_wait(j->bar);
+  j->t0_mine = getTimeMicroseconds64();
+  if (j->kind == 3)
+    CK(wino_conv3x3_bn_relu(d_in, d_U, d_bias, d_scale, d_out, n, C, K, 1, NULL));
+  else
+    CK(wino_conv1x1_bn(d_in, d_w, d_bias, d_scale, d_out, (long)n * PQ * PQ, C, K, j->relu, NULL));
+  CK(wino_device_synchronize());
+  j->t1_mine = getTimeMicroseconds64();
+
+  /* 3. copy back */
+  CK(wino_memcpy_d2h(j->h_out, d_out, out_elems * 4));
+
+  /* comparator on the same device and data */
+  if (j->kind == 3) CK(wino_memcpy_h2d(d_w, j->h_w_cmp, wc_elems * 4));
+  CK(wino_device_synchronize());
+  if (j->bar) pthread_barrier_wait(j->bar);
+  j->t0_cmp = getTimeMicroseconds64();
+  if (j->kind == 3)
+    CK(wino_conv3x3_direct(d_in, d_w, d_bias, d_scale, d_cmp, n, C, K, 1, NULL));
+  else
+    CK(wino_conv1x1_direct(d_in, d_w, d_bias, d_scale, d_cmp, (long)n * PQ * PQ, C, K, j->relu, NULL));
+  CK(wino_device_synchronize());
+  j->t1_cmp = getTimeMicroseconds64();
+  CK(wino_memcpy_d2h(j->h_cmp, d_cmp, out_elems * 4));
+
+  wino_free(d_in); wino_free(d_out); wino_free(d_cmp); wino_free(d_bias);
+  wino_free(d_scale); wino_free(d_w); wino_free(d_U);
+  return NULL;
+}
+
+/* ---------------------------------------------------------------- one layer call */
+static int clamp16(uint64_t us) { return us > 0xFFFFu ? 0xFFFF : (int)us; }
+
+static int run_layer(int kind, int C, int K, int relu) {
+  const int N = wino_driver_get_batch();
+  int G = wino_driver_get_gpus();
+  if (G > N) G = N;
+  int have = 0;
+  CK(wino_device_count(&have));
+  if (have < G) {
+    printf("HIP failure: %d GPU(s) requested, %d visible\n", G, have);
+    exit(EXIT_FAILURE);
+  }
+  char name[256], name2[256];
+  float *h_in, *h_w_wino, *h_w_cmp, *h_bias, *h_scale;
+  size_t in_per, out_per;
+  if (kind == 3) {
+    snprintf(name, sizeof name, WINO_F_INPUT_3X3, C);
+    snprintf(name2, sizeof name2, WINO_F_INPUT_3X3_BATCH, C, N);
+    in_per = (size_t)HW * HW * C; out_per = (size_t)HW * HW * K;
+    h_in = load_batched(name, name2, (int)in_per, C, N);
+    snprintf(name, sizeof name, WINO_F_WEIGHT_WINOGRAD, C, K);
+    h_w_wino = get_parameter(name, 36 * C * K);
+    snprintf(name, sizeof name, WINO_F_WEIGHT_NCHW, C, K);
+    h_w_cmp = get_parameter(name, 9 * C * K);
+    snprintf(name, sizeof name, WINO_F_BN_BIAS_FOLDED, K);
+    h_bias = get_parameter(name, K);
+    snprintf(name, sizeof name, WINO_F_BN_SCALE_FOLDED, K);
+    h_scale = get_parameter(name, K);
+  } else {
+    /* every 1x1 test reads a prefix of the _1024 files (Kernel128_one.cu:58-64) */
+    in_per = (size_t)PQ * PQ * C; out_per = (size_t)PQ * PQ * K;
+    h_in = load_batched(WINO_F_ONE_INPUT, NULL, (int)in_per, C, N);
+    h_w_wino = get_parameter(WINO_F_ONE_WEIGHT, C * K);
+    h_w_cmp = h_w_wino;
+    h_bias = get_parameter(WINO_F_ONE_BN_BIAS, K);
+    h_scale = get_parameter(WINO_F_ONE_BN_SCALE, K);
+  }
+  float* h_out = (float*)malloc(out_per * N * sizeof(float));
+  float* h_cmp = (float*)malloc(out_per * N * sizeof(float));
+  if (!h_out || !h_cmp) { printf("Bad Malloc\n"); exit(0); }
+
+  job_t jobs[MAX_GPUS];
+  pthread_t th[MAX_GPUS];
+  pthread_barrier_t bar;
+  if (G > 1) pthread_barrier_init(&bar, NULL, (unsigned)G);
+  for (int g = 0; g < G; ++g) {
+    const int n0 = (int)((long)N * g / G), n1 = (int)((long)N * (g + 1) / G);
+    job_t* j = &jobs[g];
+    memset(j, 0, sizeof *j);
+    j->device = g; j->kind = kind; j->n0 = n0; j->n = n1 - n0;
+    j->C = C; j->K = K; j->relu = relu;
+    j->h_in = h_in + in_per * n0; j->h_w_wino = h_w_wino; j->h_w_cmp = h_w_cmp;
+    j->h_bias = h_bias; j->h_scale = h_scale;
+    j->h_out = h_out + out_per * n0; j->h_cmp = h_cmp + out_per * n0;
+    j->bar = G > 1 ? &bar : NULL;
+  }
+  if (G == 1) {
+    job_main(&jobs[0]);
+  } else {
+    for (int g = 0; g < G; ++g) pthread_create(&th[g], NULL, job_main, &jobs[g]);
+    for (int g = 0; g < G; ++g) pthread_join(th[g], NULL);
+    pthread_barrier_destroy(&bar);
+  }
+  uint64_t s_m = jobs[0].t0_mine, e_m = jobs[0].t1_mine, s_c = jobs[0].t0_cmp, e_c = jobs[0].t1_cmp;
+  for (int g = 1; g < G; ++g) {
+    if (jobs[g].t0_mine < s_m) s_m = jobs[g].t0_mine;
+    if (jobs[g].t1_mine > e_m) e_m = jobs[g].t1_mine;
+    if (jobs[g].t0_cmp < s_c) s_c = jobs[g].t0_cmp;
+    if (jobs[g].t1_cmp > e_c) e_c = jobs[g].t1_cmp;
+  }
+  const uint64_t mine_us = e_m - s_m, cmp_us = e_c - s_c;
+
+  /* diff, reference checker semantics per image (util.c:46-63): 3x3 output is padded
+   * (shift 1) against an unpadded comparator; 1x1 is unpadded on both sides (shift 0) */
+  float max_err = 0.f, big = 0.f;
+  long err_cnt = 0;
+  float* interior = (float*)malloc((size_t)PQ * PQ * K * sizeof(float));
+  for (int n = 0; n < N; ++n) {
+    const float* a = h_out + out_per * n;
+    const float* b = h_cmp + out_per * n;
+    float m;
+    if (kind == 3) {
+      for (int y = 0; y < PQ; ++y)
+        memcpy(interior + (size_t)y * PQ * K, b + ((size_t)(y + 1) * HW + 1) * K, (size_t)PQ * K * sizeof(float));
+      m = output_checker_accumulate(a, interior, PQ, K, 1, &max_err, &err_cnt);
+      /* the ring of the custom output must be exactly zero */
+      for (int y = 0; y < HW; ++y)
+        for (int x = 0; x < HW; ++x)
+          if (y == 0 || y == HW - 1 || x == 0 || x == HW - 1)
+            for (int k = 0; k < K; ++k)
+              if (a[((size_t)y * HW + x) * K + k] != 0.f) { ++err_cnt; if (max_err < 1.f) max_err = 1.f; }
+    } else {
+      m = output_checker_accumulate(a, b, PQ, K, 0, &max_err, &err_cnt);
+    }
+    if (m > big) big = m;
+  }
+  free(interior);
+
+  if (!quiet()) {
+    printf("TotalTime = %d us\n", (int)mine_us);
+    printf("hipSuccess\n");
+    printf("Direct TotalTime = %d us\n", (int)cmp_us);
+    printf("hipSuccess\n");
+    printf("[max_error: %f][error_cnt: %d]\n", max_err, (int)err_cnt);
+  }
+  memset(&g_last, 0, sizeof g_last);
+  g_last.mine_us = (double)mine_us;
+  g_last.comparator_us = (double)cmp_us;
+  g_last.max_abs_err = max_err;
+  g_last.max_rel_err = big > 0.f ? max_err / big : 0.0;
+  g_last.error_cnt = err_cnt;
+  g_last.flops = 2.0 * N * PQ * PQ * (double)K * C * (kind == 3 ? 9 : 1);
+  g_last.N = N;
+  g_last.gpus = G;
+
+  free(h_in); free(h_w_wino); if (h_w_cmp != h_w_wino) free(h_w_cmp);
+  free(h_bias); free(h_scale); free(h_out); free(h_cmp);
+  return (clamp16(mine_us) << 16) | clamp16(cmp_us);
+}
+
+/* ---------------------------------------------------------------- the six entry points */
+int kernel_128(void) { return run_layer(3, 128, 128, 1); }
+int kernel_256(void) { return run_layer(3, 256, 256, 1); }
+int kernel_128_1_in(void) { return run_layer(1, 512, 128, 1); }   /* ReLU: Kernel128_one.cu:53 */
+int kernel_128_1_out(void) { return run_layer(1, 128, 512, 0); }  /* no ReLU: :271-272 */
+int kernel_256_1_in(void) { return run_layer(1, 1024, 256, 1); }  /* ReLU: Kernel256_one.cu:55 */
+int kernel_256_1_out(void) { return run_layer(1, 256, 1024, 0); } /* no ReLU: :273 */

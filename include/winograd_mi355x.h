@@ -1,0 +1,147 @@
+/*
+ * winograd_mi355x.h -- C-ABI of libwinograd_mi355x.so
+ *
+ * MI355X (gfx950) native fused Winograd F(2x2,3x3) conv + BN + ReLU and
+ * 1x1-conv GEMM + BN (+ReLU).  Plain C: pointers, sizes, ints.  No HIP or
+ * torch types; a stream is passed as an opaque `void*` (a hipStream_t, NULL =
+ * the default stream).  All `float*` tensor arguments are DEVICE pointers
+ * unless a name ends in `_host`.
+ *
+ * Every function returns WINO_OK (0) or a negative WINO_E_* code;
+ * wino_last_error_string() describes the last failure of the calling thread.
+ * Nothing here falls back to the CPU: without a usable GPU every compute entry
+ * point fails with WINO_E_HIP.
+ *
+ * Reference interface each group replaces (paths into bssrdf/CUDA-Winograd):
+ *   runtime plumbing   cudaSetDevice (Test.c:15), cudaMalloc/cudaMemset/cudaMemcpy/
+ *                      cudaFree/cudaDeviceSynchronize/cudaGetErrorName
+ *                      (Kernel128_winograd.cu:236-286)
+ *   filter transforms  data_generator.py:63-78 (offline G g G^T)
+ *   wino_conv3x3_*     the three launches kernel_{128,256}_winograd_BtdB ->
+ *                      kernel_*_OuterProduct_* -> kernel_*_winograd_AtIA
+ *                      (Kernel128_winograd.cu:263-265, Kernel256_winograd.cu:266-268)
+ *   wino_conv1x1_bn    kernel_512_one_128 / kernel_128_one_512 (Kernel128_one.cu:98,316),
+ *                      kernel_1024_one_256 / kernel_256_one_1024 (Kernel256_one.cu:100,318)
+ *   wino_conv3x3_direct  the comparator role cuDNN plays in the reference
+ *                      (Kernel128_winograd.cu:382-404), as an independent
+ *                      non-Winograd GPU kernel
+ * The six argument-less reference entry points themselves are declared in
+ * Kernel128_winograd.h, Kernel256_winograd.h, Kernel128_one.h, Kernel256_one.h
+ * (same directory) and exported by the same library.
+ */
+#ifndef WINOGRAD_MI355X_H
+#define WINOGRAD_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WINO_ABI_VERSION 1
+
+enum {
+  WINO_OK = 0,
+  WINO_E_HIP = -1,       /* a HIP runtime call failed (no device, OOM, launch error) */
+  WINO_E_SHAPE = -2,     /* unsupported / inconsistent shape argument */
+  WINO_E_ARG = -3,       /* NULL pointer, bad enum, workspace too small */
+};
+
+/* geometry fixed by the reference's 14x14 stage */
+#define WINO_HW 16        /* padded input / output extent */
+#define WINO_PQ 14        /* valid output extent          */
+#define WINO_TILES 49     /* F(2x2) tiles per image (7x7) */
+
+typedef void* wino_stream_t;
+
+/* ---- runtime plumbing (thin wrappers so that C hosts need no HIP headers) ---- */
+int wino_abi_version(void);
+const char* wino_last_error_string(void);
+int wino_device_count(int* count);
+int wino_set_device(int device);
+int wino_device_name(int device, char* buf, size_t buflen);
+int wino_malloc(void** dptr, size_t bytes);
+int wino_free(void* dptr);
+int wino_memset(void* dptr, int value, size_t bytes);
+int wino_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int wino_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int wino_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes);
+int wino_device_synchronize(void);
+int wino_stream_create(wino_stream_t* stream);
+int wino_stream_destroy(wino_stream_t stream);
+int wino_stream_synchronize(wino_stream_t stream);
+/* events: timing on the stream the kernels run on (hipEvent based) */
+int wino_event_create(void** event);
+int wino_event_destroy(void* event);
+int wino_event_record(void* event, wino_stream_t stream);
+int wino_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+
+/* ---- 3x3: Winograd-domain filters ------------------------------------------ */
+/* Number of floats of the packed F(2x2,3x3) filter buffer `U` for C in-channels and
+ * K out-channels (= 16*C*K).  Its internal layout ([C/8][K/64][16][64][8], LDS-bank
+ * swizzled) is private to the library. */
+size_t wino_filter_f2_elems(int C, int K);
+/* w_kcrs: [K][C][3][3] (weight_NCHW_C_K.bin) -> U.  G g G^T evaluated in fp64, stored fp32. */
+int wino_filter_transform_f2(const float* w_kcrs, float* U, int C, int K, wino_stream_t s);
+/* u36: the reference's pre-transformed F(4x4,3x3) weights [36][C][K]
+ * (weight_winograd_C_K.bin, data_generator.py:63-78).  The 3x3 taps are recovered
+ * exactly (g = L u L^T, L = left inverse of the reference's G) and re-transformed to
+ * F(2x2,3x3), so the reference's weight file is consumed as is. */
+int wino_filter_import_f4(const float* u36, float* U, int C, int K, wino_stream_t s);
+
+/* ---- 3x3 conv + folded BN + ReLU ---------------------------------------------
+ * in  [N][16][16][C]   NHWC, ring included (a valid conv of the 16x16 image)
+ * U   from wino_filter_transform_f2 / wino_filter_import_f4
+ * out [N][16][16][K]   14x14 result at [1..14][1..14], ring written as 0
+ *                       (= the next 3x3 layer's padded input, Kernel128_winograd.cu:163)
+ * out = relu(bnScale[k] * conv + bnBias[k]);  argument order (in, bias, scale, out)
+ * follows kernel_*_winograd_AtIA (Kernel128_winograd.cu:123).
+ * Constraints: C % 8 == 0, K % 64 == 0, N >= 1.  One launch, no workspace. */
+int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
+                         const float* bnScale, float* out, int N, int C, int K, int relu,
+                         wino_stream_t s);
+
+/* Independent comparator: direct (non-Winograd) 3x3 conv + BN + ReLU on the GPU,
+ * w_kcrs [K][C][3][3]; same in/out layout as above.  Slow by design. */
+int wino_conv3x3_direct(const float* in, const float* w_kcrs, const float* bnBias,
+                        const float* bnScale, float* out, int N, int C, int K, int relu,
+                        wino_stream_t s);
+
+/* ---- 1x1 conv as GEMM + folded BN (+ReLU) --------------------------------------
+ * A [M][Cin] (M = N*196 pixels, HWC flat), B [Cin][Kout] row-major, C [M][Kout].
+ * C = bnScale[k]*(A.B) + bnBias[k], ReLU if `relu`.  Argument order as the reference
+ * kernels (A, B, bnBias, bnScale, C), Kernel128_one.cu:24.
+ * Constraints: Cin % 32 == 0, Kout % 128 == 0, M >= 1 (any M: the last row tile is ragged). */
+int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                    float* C, long M, int Cin, int Kout, int relu, wino_stream_t s);
+/* Independent comparator for the 1x1 layers: one thread per output, fp32 FMA loop. */
+int wino_conv1x1_direct(const float* A, const float* B, const float* bnBias,
+                        const float* bnScale, float* C, long M, int Cin, int Kout, int relu,
+                        wino_stream_t s);
+
+/* ---- driver configuration for the argument-less reference entry points ---------
+ * kernel_128() & co take no arguments (Kernel128_winograd.h:20); batch size, GPU count
+ * and verbosity come from here (defaults N=1, 1 GPU = the reference's behaviour) or
+ * from the environment (WINO_BATCH, WINO_GPUS, WINO_QUIET) at first use. */
+int wino_driver_set_batch(int N);
+int wino_driver_set_gpus(int ngpu);
+int wino_driver_set_quiet(int quiet);
+int wino_driver_get_batch(void);
+int wino_driver_get_gpus(void);
+/* Last call's unpacked results (the packed int overflows at 65.5 ms, Test.c:46-47). */
+typedef struct {
+  double mine_us;        /* custom path, wall clock launch..sync (max over GPUs) */
+  double comparator_us;  /* direct-conv comparator, same protocol */
+  double max_abs_err;    /* output_checker semantics (util.c:46-63) over all images */
+  double max_rel_err;    /* max|diff| / max|comparator| */
+  long error_cnt;        /* |diff| > 1e-5, reference threshold */
+  double flops;          /* algorithmic FLOPs of the layer call (2*N*P*Q*K*C*R*S) */
+  int N, gpus;
+} wino_driver_result;
+int wino_driver_last_result(wino_driver_result* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WINOGRAD_MI355X_H */

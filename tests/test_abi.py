@@ -1,0 +1,133 @@
+"""The C-ABI library loads, exports every symbol include/*.h declares, and its host-side
+logic (util.c helpers, driver configuration, argument checking) behaves like the
+reference's.  No GPU compute is attempted here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, ptr
+
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def _declared_functions():
+    names = set()
+    for h in sorted(os.listdir(INCLUDE)):
+        if not h.endswith(".h"):
+            continue
+        src = open(os.path.join(INCLUDE, h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"^[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", src, flags=re.M):
+            names.add(m.group(1))
+    return names
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    declared = _declared_functions()
+    assert {"wino_conv3x3_bn_relu", "wino_conv1x1_bn", "kernel_128", "kernel_256_1_out",
+            "get_parameter", "output_checker"} <= declared
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    assert declared == set(pkg.ABI_SYMBOLS), declared ^ set(pkg.ABI_SYMBOLS)
+    assert L.wino_abi_version() == 1
+
+
+def test_exported_table_has_no_torch_types():
+    out = subprocess.check_output(["nm", "-D", "--defined-only",
+                                   os.path.join(ROOT, "cuda-winograd_amd", "libwinograd_mi355x.so")]).decode()
+    syms = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert "wino_conv3x3_bn_relu" in syms and "kernel_128" in syms
+    assert not [s for s in syms if "torch" in s.lower() or "at::" in s]
+
+
+def test_get_parameter_and_transpose(pkg, tmp_path):
+    L = pkg.lib()
+    L.get_parameter.restype = ctypes.POINTER(ctypes.c_float)
+    L.get_parameter.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.transpose.restype = ctypes.POINTER(ctypes.c_float)
+    L.transpose.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_int]
+    a = np.arange(12, dtype="<f4")
+    p = tmp_path / "x.bin"
+    a.tofile(p)
+    buf = L.get_parameter(str(p).encode(), 12)
+    got = np.ctypeslib.as_array(buf, shape=(12,)).copy()
+    np.testing.assert_array_equal(got, a)
+    # transpose(weight, h, w): input [w][h] -> output [h][w] (util.c:15-26), frees its input
+    t = L.transpose(buf, 3, 4)
+    got_t = np.ctypeslib.as_array(t, shape=(3, 4)).copy()
+    np.testing.assert_array_equal(got_t, a.reshape(4, 3).T)
+
+
+def test_get_parameter_missing_file_exits_zero(tmp_path):
+    """Reference behaviour: message + exit(0) (util.c:30-39)."""
+    code = ("import ctypes,sys;L=ctypes.CDLL(sys.argv[1]);"
+            "L.get_parameter.argtypes=[ctypes.c_char_p,ctypes.c_int];L.get_parameter(b'/nonexistent/x.bin',4);"
+            "print('survived')")
+    r = subprocess.run(["python", "-c", code, os.path.join(ROOT, "cuda-winograd_amd", "libwinograd_mi355x.so")],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "Bad file path" in r.stdout and "survived" not in r.stdout
+
+
+def test_output_checker_matches_oracle(pkg, O, capfd):
+    L = pkg.lib()
+    L.output_checker.restype = ctypes.c_float
+    L.output_checker.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    rng = np.random.RandomState(2)
+    B = rng.rand(14, 14, 16).astype(np.float32)
+    A = np.zeros((16, 16, 16), np.float32)
+    A[1:15, 1:15] = B
+    A[2, 3, 4] += 0.25
+    A[9, 9, 0] -= 2e-5
+    m = L.output_checker(ptr(A), ptr(B), 14, 16, 1)
+    want_m, want_c = O.output_checker(A, B, 14, 16, 1)
+    assert abs(m - want_m) < 1e-7
+    ctypes.CDLL(None).fflush(None)  # C stdio is block-buffered when captured
+    out = capfd.readouterr().out
+    assert out.strip() == "[max_error: %f][error_cnt: %d]" % (want_m, want_c)
+
+
+def test_driver_configuration(pkg):
+    L = pkg.lib()
+    assert L.wino_driver_set_batch(0) != 0 and L.wino_driver_set_gpus(0) != 0
+    assert L.wino_driver_set_batch(128) == 0 and L.wino_driver_get_batch() == 128
+    assert L.wino_driver_set_gpus(8) == 0 and L.wino_driver_get_gpus() == 8
+    L.wino_driver_set_batch(1); L.wino_driver_set_gpus(1)
+
+
+def test_argument_checks_fail_loudly(pkg):
+    L = pkg.lib()
+    assert L.wino_filter_f2_elems(256, 256) == 16 * 256 * 256
+    one = ctypes.c_void_p(16)  # never dereferenced: shape checks come first
+    assert L.wino_conv3x3_bn_relu(None, None, None, None, None, 1, 128, 128, 1, None) == -3
+    assert L.wino_conv3x3_bn_relu(one, one, one, one, one, 1, 100, 128, 1, None) == -2
+    assert L.wino_conv3x3_bn_relu(one, one, one, one, one, 0, 128, 128, 1, None) == -2
+    assert b"need C" in L.wino_last_error_string() or b"batch" in L.wino_last_error_string()
+    assert L.wino_conv1x1_bn(one, one, one, one, one, 196, 100, 128, 1, None) == -2
+    assert L.wino_conv1x1_bn(one, one, one, one, one, 196, 128, 100, 1, None) == -2
+
+
+def test_python_ops_reject_cpu_tensors(pkg):
+    """No CPU fallback: the operator wrappers refuse host tensors."""
+    import torch
+    x = torch.zeros(1, 16, 16, 128)
+    with pytest.raises(pkg.WinoError):
+        pkg.conv3x3_bn_relu(x, torch.zeros(16 * 128 * 128), torch.zeros(128), torch.zeros(128))
+    with pytest.raises(pkg.WinoError):
+        pkg.conv1x1_bn(torch.zeros(4, 128), torch.zeros(128, 128), torch.zeros(128), torch.zeros(128), True)
+
+
+def test_shard_range_partitions(pkg):
+    for N in (1, 7, 128, 1024):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                a, b = pkg.shard_range(N, r, world)
+                cover += list(range(a, b))
+            assert cover == list(range(N))
+    with pytest.raises(ValueError):
+        pkg.shard_range(8, 2, 2)
