@@ -23,7 +23,7 @@ all: $(LIB) Test
 $(BUILD):
 	mkdir -p $(BUILD)
 
-$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/wino_common.h include/winograd_mi355x.h | $(BUILD)
+$(BUILD)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/winograd_mi355x.h | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(BUILD)/%.o: $(HOST)/%.c include/winograd_mi355x.h include/util.h | $(BUILD)

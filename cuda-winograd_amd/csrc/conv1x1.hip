@@ -28,7 +28,6 @@ constexpr int B_BYTES = BK * BN * 4;     // 16384
 constexpr int STAGE = A_BYTES + B_BYTES; // 30720
 constexpr int LDS_BYTES = 2 * STAGE;     // 61440
 constexpr int A_WAVE_INSTR = A_BYTES / 1024;  // 14
-constexpr int B_WAVE_INSTR = B_BYTES / 1024;  // 16
 
 __global__ void __launch_bounds__(NT, 2)
 conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,

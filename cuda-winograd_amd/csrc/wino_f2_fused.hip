@@ -27,22 +27,19 @@
 // LDS bank-conflict avoidance is done by XOR-permuting 16-byte units, applied on the DMA
 // *source* address for the raw patches (the LDS destination of an LDS-DMA is lane-linear)
 // and baked into the packed filter layout for U.
-#include "wino_common.h"
+#include "wino_f2_fused_kernel.h"
 
 #include <atomic>
 
 namespace wino {
 namespace {
 
-constexpr int TB = 64;                       // tiles per workgroup
-constexpr int KB = 64;                       // out-channels per workgroup
-constexpr int BC = 8;                        // in-channels per pipeline stage
-constexpr int NTHREADS = 512;
-constexpr int RAW_BYTES = TB * 16 * BC * 4;  // 32768
-constexpr int U_BYTES = 16 * KB * BC * 4;    // 32768
-constexpr int STAGE_BYTES = RAW_BYTES + U_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // 131072
-constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
+using namespace fused;
+
+#ifndef WINO_PF
+#define WINO_PF 2    // filter-fragment prefetch distance (points)     } tuned on MI355X with
+#define WINO_DMA0 8  // first point-step that issues an LDS-DMA piece    } tools/ablate_fused
+#endif
 
 // Position (in floats, 0..7) inside the 8-channel group of the packed filter at which
 // channel `cl` (0..7) of out-channel `kl` (0..63 within the k-block) is stored: the
@@ -123,208 +120,6 @@ __global__ void filter_import_f4_kernel(const float* __restrict__ u36, float* __
   for (int e = 0; e < 16; e++) U[u_index(C, K, e, c, k)] = (float)u[e >> 2][e & 3];
 }
 
-// ---------------------------------------------------------------------------------
-// The fused kernel
-// ---------------------------------------------------------------------------------
-struct TileCoord {
-  int n, ty, tx;
-};
-__device__ __forceinline__ TileCoord decode_tile(int g) {
-  TileCoord t;
-  t.n = g / WINO_TILES;
-  const int rem = g - t.n * WINO_TILES;
-  t.ty = rem / 7;
-  t.tx = rem - t.ty * 7;
-  return t;
-}
-
-__global__ void __launch_bounds__(NTHREADS, 2)
-wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
-                     const float* __restrict__ bnBias, const float* __restrict__ bnScale,
-                     float* __restrict__ out, int N, int C, int K, int relu, int nTB) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  // XCD-aware block -> (tile block, k block): blocks b and b+8 share an XCD (its L2), so the
-  // K/64 k-blocks that read the same input tiles are placed on the same XCD back to back.
-  const int KBLK = K >> 6;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int kb = slot % KBLK;
-  const int tb = (slot / KBLK) * 8 + xcd;
-  if (tb >= nTB) return;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wt = w >> 1;  // which 16-tile block of the 64
-  const int wk = w & 1;   // which 32-channel half of the 64
-  const int totalTiles = N * WINO_TILES;
-
-  // ---- DMA source offsets (loop invariant) ------------------------------------
-  // raw stage layout: [tile 0..63][unit' 0..31] of 16 B; unit' = px'*2 + half'.
-  // LDS unit (t, px', half') holds pixel px = px' ^ (t&7), channel half = half' ^ bit3(t).
-  // wave-instruction q = 8*j + w (j = 0..3) covers tiles 2q, 2q+1.
-  const float* raw_src[4];
-  {
-    const int up = lane & 31;
-    const int pxp = up >> 1, halfp = up & 1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int tl = 16 * j + 2 * w + (lane >> 5);
-      const int px = pxp ^ (tl & 7);
-      const int half = halfp ^ ((tl >> 3) & 1);
-      int g = tb * TB + tl;
-      g = g < totalTiles ? g : totalTiles - 1;  // clamp: padded rows read a valid tile
-      const TileCoord tc = decode_tile(g);
-      const int y = 2 * tc.ty + (px >> 2), x = 2 * tc.tx + (px & 3);
-      raw_src[j] = in + ((size_t)(tc.n * WINO_HW + y) * WINO_HW + x) * C + half * 4;
-    }
-  }
-  const float* u_src = Uq + (size_t)kb * U_CHUNK_FLOATS + w * 256 + lane * 4;
-  const size_t u_chunk_stride = (size_t)KBLK * U_CHUNK_FLOATS;
-
-  auto issue = [&](int stage, int chunk) {
-    char* sbase = smem + stage * STAGE_BYTES;
-#pragma unroll
-    for (int j = 0; j < 4; j++) dma16(raw_src[j] + chunk * BC, sbase + (8 * j + w) * 1024);
-    const float* us = u_src + (size_t)chunk * u_chunk_stride;
-#pragma unroll
-    for (int j = 0; j < 4; j++) dma16(us + j * 2048, sbase + RAW_BYTES + (8 * j + w) * 1024);
-  };
-
-  // ---- fragment read addresses (loop invariant) ---------------------------------
-  const int t16 = lane & 15, h = lane >> 4;
-  // A: tile row tl = wt*16 + t16; 8-byte quarter h holds channels 2h, 2h+1 of the chunk
-  const int a_base = (wt * 16 + t16) * 512 + ((h ^ (((t16 >> 3) & 1) << 1)) << 3);
-  const int a_sw = t16 & 7;
-  // B: k_local = wk*32 + cb*16 + t16
-  int b_base[2];
-#pragma unroll
-  for (int cb = 0; cb < 2; cb++) {
-    const int kl = wk * 32 + cb * 16 + t16;
-    b_base[cb] = RAW_BYTES + kl * 32 + ((h ^ (((kl >> 3) & 1) << 1)) << 3);
-  }
-
-  f32x4 acc[16][2];
-#pragma unroll
-  for (int e = 0; e < 16; e++) {
-    acc[e][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[e][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-
-  const int nchunks = C / BC;
-  issue(0, 0);
-  for (int it = 0; it < nchunks; ++it) {
-    wait_vmem_all();   // my own DMA pieces of chunk `it` have landed
-    __syncthreads();   // everyone's have; everyone is also done reading the other stage
-    if (it + 1 < nchunks) issue((it + 1) & 1, it + 1);
-
-    const char* st = smem + (it & 1) * STAGE_BYTES;
-
-    // ---- A operand: load the 4x4 patch (2 channels per lane) and transform ------
-    f32x2 d[16];
-#pragma unroll
-    for (int px = 0; px < 16; px++)
-      d[px] = *(const f32x2*)(st + a_base + (((px & 7) ^ a_sw) << 5) + ((px >> 3) << 8));
-    f32x2 v[16];
-    {
-      f32x2 tmp[16];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {  // B^T d : combine patch rows
-        tmp[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-        tmp[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-        tmp[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-        tmp[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {  // (B^T d) B : combine patch columns
-        v[i * 4 + 0] = tmp[i * 4 + 0] - tmp[i * 4 + 2];
-        v[i * 4 + 1] = tmp[i * 4 + 1] + tmp[i * 4 + 2];
-        v[i * 4 + 2] = tmp[i * 4 + 2] - tmp[i * 4 + 1];
-        v[i * 4 + 3] = tmp[i * 4 + 1] - tmp[i * 4 + 3];
-      }
-    }
-
-    // ---- 16 points x 2 k-blocks x 2 k-steps of v_mfma_f32_16x16x4_f32 ------------
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const f32x2 b0 = *(const f32x2*)(st + b_base[0] + e * 2048);
-      const f32x2 b1 = *(const f32x2*)(st + b_base[1] + e * 2048);
-      acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e].x, b0.x, acc[e][0], 0, 0, 0);
-      acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e].x, b1.x, acc[e][1], 0, 0, 0);
-      acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e].y, b0.y, acc[e][0], 0, 0, 0);
-      acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e].y, b1.y, acc[e][1], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue: A^T m A, BN, ReLU, store (C/D layout: col = lane&15, row = 4*(lane>>4)+r)
-  float sc[2], bi[2];
-  int kcol[2];
-#pragma unroll
-  for (int cb = 0; cb < 2; cb++) {
-    kcol[cb] = kb * KB + wk * 32 + cb * 16 + t16;
-    sc[cb] = bnScale[kcol[cb]];
-    bi[cb] = bnBias[kcol[cb]];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int g = tb * TB + wt * 16 + 4 * h + r;
-    if (g >= totalTiles) continue;
-    const TileCoord tc = decode_tile(g);
-    float* img = out + (size_t)tc.n * WINO_HW * WINO_HW * K;
-    const int oy = 1 + 2 * tc.ty, ox = 1 + 2 * tc.tx;
-#pragma unroll
-    for (int cb = 0; cb < 2; cb++) {
-      float t0[4], t1[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float m0 = acc[0 * 4 + j][cb][r], m1 = acc[1 * 4 + j][cb][r];
-        const float m2 = acc[2 * 4 + j][cb][r], m3 = acc[3 * 4 + j][cb][r];
-        t0[j] = m0 + m1 + m2;
-        t1[j] = m1 - m2 - m3;
-      }
-      float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
-      float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
-      y00 = sc[cb] * y00 + bi[cb];
-      y01 = sc[cb] * y01 + bi[cb];
-      y10 = sc[cb] * y10 + bi[cb];
-      y11 = sc[cb] * y11 + bi[cb];
-      if (relu) {
-        y00 = fmaxf(y00, 0.f);
-        y01 = fmaxf(y01, 0.f);
-        y10 = fmaxf(y10, 0.f);
-        y11 = fmaxf(y11, 0.f);
-      }
-      float* o = img + kcol[cb];
-      o[((oy)*WINO_HW + ox) * K] = y00;
-      o[((oy)*WINO_HW + ox + 1) * K] = y01;
-      o[((oy + 1) * WINO_HW + ox) * K] = y10;
-      o[((oy + 1) * WINO_HW + ox + 1) * K] = y11;
-      // zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:163,243)
-      if (tc.ty == 0) {
-        o[(ox)*K] = 0.f;
-        o[(ox + 1) * K] = 0.f;
-        if (tc.tx == 0) o[0] = 0.f;
-        if (tc.tx == 6) o[15 * K] = 0.f;
-      }
-      if (tc.ty == 6) {
-        o[(15 * WINO_HW + ox) * K] = 0.f;
-        o[(15 * WINO_HW + ox + 1) * K] = 0.f;
-        if (tc.tx == 0) o[(15 * WINO_HW) * K] = 0.f;
-        if (tc.tx == 6) o[(15 * WINO_HW + 15) * K] = 0.f;
-      }
-      if (tc.tx == 0) {
-        o[((oy)*WINO_HW) * K] = 0.f;
-        o[((oy + 1) * WINO_HW) * K] = 0.f;
-      }
-      if (tc.tx == 6) {
-        o[((oy)*WINO_HW + 15) * K] = 0.f;
-        o[((oy + 1) * WINO_HW + 15) * K] = 0.f;
-      }
-    }
-  }
-}
-
 }  // namespace
 }  // namespace wino
 
@@ -371,13 +166,13 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
   int dev = 0;
   WINO_HIP(hipGetDevice(&dev));
   if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
-    WINO_HIP(hipFuncSetAttribute((const void*)wino_f2_fused_kernel,
+    WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<0, WINO_PF, WINO_DMA0>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done.fetch_or(1ull << (dev & 63));
   }
   const int nTB = (N * WINO_TILES + TB - 1) / TB;
   const int grid = 8 * (K / KB) * ((nTB + 7) / 8);
-  hipLaunchKernelGGL(wino_f2_fused_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s,
+  hipLaunchKernelGGL((wino_f2_fused_kernel<0, WINO_PF, WINO_DMA0>), dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s,
                      in, U, bnBias, bnScale, out, N, C, K, relu, nTB);
   return launch_status("wino_f2_fused_kernel");
 }

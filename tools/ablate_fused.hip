@@ -1,0 +1,69 @@
+// Developer tool: prices the parts of the fused Winograd kernel by timing ablated variants
+// (see ABLATE in csrc/wino_f2_fused_kernel.h).  Not part of the library.
+//   hipcc --offload-arch=gfx950 -O3 -Iinclude -Icuda-winograd_amd/csrc tools/ablate_fused.hip -o tools/ablate_fused
+#include "wino_f2_fused_kernel.h"
+
+#include <cstdlib>
+#include <algorithm>
+#include <vector>
+
+namespace wino { void set_error(const char*, ...) {} int hip_fail(hipError_t, const char*) { return -1; } }
+using namespace wino::fused;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int AB, int PF, int DMA0 = 0>
+float run(const float* in, const float* U, const float* b, const float* s, float* out, int N, int C, int K, int reps) {
+  CK(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<AB, PF, DMA0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  const int nTB = (N * 49 + TB - 1) / TB;
+  const int grid = 8 * (K / KB) * ((nTB + 7) / 8);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; i++)
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB, PF, DMA0>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; i++)
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB, PF, DMA0>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / reps;
+}
+
+int main(int argc, char** argv) {
+  const int C = argc > 1 ? atoi(argv[1]) : 256, K = C;
+  std::vector<int> Ns = {1, 83, 128};
+  const size_t maxN = 256;
+  float *in, *U, *b, *s, *out;
+  CK(hipMalloc(&in, maxN * 256 * C * 4)); CK(hipMalloc(&out, maxN * 256 * K * 4));
+  CK(hipMalloc(&U, (size_t)16 * C * K * 4)); CK(hipMalloc(&b, K * 4)); CK(hipMalloc(&s, K * 4));
+  std::vector<float> h(maxN * 256 * C);
+  for (auto& x : h) x = (float)rand() / RAND_MAX - 0.5f;
+  CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(U, h.data(), (size_t)16 * C * K * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b, h.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + K, K * 4, hipMemcpyHostToDevice));
+  printf("C=K=%d   us per launch; WGs = 4*ceil(N*49/64) (K/64 k-blocks)\n", C);
+  printf("%6s %6s | %8s %8s %8s %8s %8s | %8s %8s\n", "N", "WGs", "dma@0", "dma@4", "dma@8", "dma@alt", "dma@8PF3", "noDMA", "noSync");
+  for (int N : Ns) {
+    const int wgs = (K / 64) * ((N * 49 + 63) / 64);
+    printf("%6d %6d | %8.1f %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f\n", N, wgs,
+           run<0, 2, 0>(in, U, b, s, out, N, C, K, 20), run<0, 2, 4>(in, U, b, s, out, N, C, K, 20),
+           run<0, 2, 8>(in, U, b, s, out, N, C, K, 20), run<0, 2, -1>(in, U, b, s, out, N, C, K, 20),
+           run<0, 3, 8>(in, U, b, s, out, N, C, K, 20),
+           run<3, 2, 0>(in, U, b, s, out, N, C, K, 20), run<8, 2, 0>(in, U, b, s, out, N, C, K, 20));
+  }
+  {  // in-kernel clock of the main loop (diagnostic build, ABLATE bit 16)
+    const int N = 128;
+    const int nTB = (N * 49 + TB - 1) / TB, wgs = nTB * (K / KB);
+    run<16, 2>(in, U, b, s, out, N, C, K, 3);
+    std::vector<unsigned long long> st((size_t)wgs * 2);
+    CK(hipMemcpy(st.data(), out + (size_t)N * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, rt = 0, cmin = 1e30, cmax = 0;
+    for (int i = 0; i < wgs; i++) { cyc += st[2 * i]; rt += st[2 * i + 1]; cmin = std::min(cmin, (double)st[2 * i]); cmax = std::max(cmax, (double)st[2 * i]); }
+    printf("main loop, N=128: in-kernel clock %.3f GHz; cycles per WG pass mean %.0f min %.0f max %.0f (= %.1f cycles per MFMA per SIMD)\n",
+           cyc / rt * 0.1, cyc / wgs, cmin, cmax, cyc / wgs / (C / 8) / 128.0);
+  }
+  return 0;
+}
