@@ -197,7 +197,15 @@ def main():
         out = torch.empty((N * 196, K), device=dev)
         step = lambda: pkg.conv1x1_bn(A, B, bias_v, scale_v, relu, out=out)
 
-    sync = lambda: torch.cuda.synchronize(dev)
+    def sync():
+        # torch.cuda.synchronize() alone sometimes returns tens of ms late when a long queue is
+        # pending (the runtime backs off to a sleeping wait); spinning on an event first keeps the
+        # wall clock honest, the synchronize() the contract asks for then returns at once.
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
+        torch.cuda.synchronize(dev)
     if world > 1:
         import torch.distributed as dist
         barrier = lambda: dist.barrier(device_ids=[local_rank])

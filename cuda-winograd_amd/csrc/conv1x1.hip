@@ -6,33 +6,90 @@
 // with A [M][Cin] (pixels x in-channels, the reference's HWC-flat activations),
 // B [Cin][Kout] row-major exactly as the reference stores it (Kernel128_one.cu:40-42).
 //
-// Tiling: workgroup = 256 threads (4 waves) computes BM=112 x BN=128 of C; K-loop over Cin
-// in steps of BK=32, two LDS stages filled by LDS-DMA.  BM = 7 MFMA row blocks because the
-// reference's M = N*196 = 2^a * 49: 112-row tiles cover it exactly (25088 = 224 * 112) and
-// 224 tiles fill one round of 256 CUs at Kout = 128.  Wave w owns columns [32w, 32w+32):
-// 7 x 2 accumulator tiles of v_mfma_f32_16x16x4_f32 (56 acc VGPRs).
+// Tiling: workgroup = 512 threads (8 waves, 2 per SIMD) computes BM=112 x BN=128 of C; the
+// K-loop runs over Cin in steps of BK (64, or 32 when Cin % 64 != 0) through two LDS stages
+// filled by LDS-DMA.  BM = 7 MFMA row blocks because the reference's M = N*196 = 2^a * 49:
+// 112-row tiles cover it exactly (25088 = 224 * 112) and 224 tiles fill one round of the 256
+// CUs at Kout = 128.  Wave w owns columns [16w, 16w+16): 7 accumulator tiles of
+// v_mfma_f32_16x16x4_f32 (28 acc VGPRs); the A fragment of a step is shared by 4 MFMAs.
 //
 // LDS images (16-byte units XOR-permuted on the DMA source side so that fragment reads are
 // bank-conflict free):
-//   A stage [112 rows][8 units]: unit' = unit ^ ((row>>1)&7); A fragments by ds_read_b128
-//   B stage [32 k][32 units]   : unit' = unit ^ (4*((k>>2)&1)); B fragments by ds_read_b32
+//   A stage [112 rows][BK/4 units]: unit' = unit ^ f(row); fragments by ds_read_b128
+//           f(row) = row & 15 (BK = 64: one 256-B bank row per A row), (row>>1) & 7 (BK = 32)
+//   B stage [BK k][32 units]      : unit' = unit ^ (4*((k>>2)&1)); fragments by ds_read_b32
+// The point loop is pinned (sched_barrier) with LDS requests two steps ahead of their use and
+// counted lgkmcnt waits, and the LDS-DMA pieces are issued one per step: see the notes in
+// wino_f2_fused_kernel.h, the same three hipcc behaviours apply here.
 #include "wino_common.h"
+
+#include <atomic>
+#include <type_traits>
 
 namespace wino {
 namespace {
 
-constexpr int BM = 112, BN = 128, BK = 32, NT = 256;
-constexpr int RB = BM / 16;              // 7 row blocks
-constexpr int A_BYTES = BM * BK * 4;     // 14336
-constexpr int B_BYTES = BK * BN * 4;     // 16384
-constexpr int STAGE = A_BYTES + B_BYTES; // 30720
-constexpr int LDS_BYTES = 2 * STAGE;     // 61440
-constexpr int A_WAVE_INSTR = A_BYTES / 1024;  // 14
+constexpr int BM = 112, BN = 128, NT = 512, NW = 8;
+constexpr int RB = BM / 16;  // 7 row blocks
 
+__device__ __forceinline__ void wait_lds1(int n) {
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0xC07F); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0xC17F); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0xC27F); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0xC37F); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0xC47F); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0xC57F); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0xC67F); break;
+    case 7: __builtin_amdgcn_s_waitcnt(0xC77F); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0xC87F); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0xC97F); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0xCA7F); break;
+    case 11: __builtin_amdgcn_s_waitcnt(0xCB7F); break;
+    case 12: __builtin_amdgcn_s_waitcnt(0xCC7F); break;
+    default: __builtin_amdgcn_s_waitcnt(0xCF7F); break;
+  }
+}
+
+template <int BK>
+struct Cfg {
+  static constexpr int S = BK / 16;                 // 16-wide k sub-chunks per stage
+  static constexpr int T = S * RB;                  // pinned steps per stage (4 MFMAs each)
+  static constexpr int UNITS = BK / 4;              // 16-byte units per A row
+  static constexpr int A_BYTES = BM * BK * 4;
+  static constexpr int B_BYTES = BK * BN * 4;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int A_PIECES = A_BYTES / 1024;   // LDS-DMA wave-instructions per stage
+  static constexpr int B_PIECES = B_BYTES / 1024;
+  static constexpr int A_PER_WAVE = (A_PIECES + NW - 1) / NW;
+  static constexpr int B_PER_WAVE = B_PIECES / NW;
+  static constexpr int ROWS_PER_PIECE = 1024 / (BK * 4);
+  static __device__ __forceinline__ int fa(int row) { return BK == 64 ? (row & 15) : ((row >> 1) & 7); }
+  // LDS requests at the top of step q: the A fragment of step q+2, then (on row block 2) the
+  // four B values of the next sub-chunk
+  static constexpr int nA(int q) { return q + 2 < T ? 1 : 0; }
+  static constexpr int nB(int q) { return (q % RB == 2 && q / RB + 1 < S) ? 4 : 0; }
+  // requests younger than the A fragment step t consumes
+  static constexpr int wait_count(int t) {
+    int after = 0;
+    if (t < 2) {
+      after = 1 - t;                                  // pre-loop block: B(0)x4, A(0), A(1)
+      for (int q = 0; q <= t; q++) after += nA(q) + nB(q);
+    } else {
+      after = nB(t - 2);
+      for (int q = t - 1; q <= t; q++) after += nA(q) + nB(q);
+    }
+    return after;
+  }
+};
+
+template <int BK>
 __global__ void __launch_bounds__(NT, 2)
 conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                   const float* __restrict__ bnBias, const float* __restrict__ bnScale,
                   float* __restrict__ Cout, long M, int Cin, int Kout, int relu, int nMB) {
+  using G = Cfg<BK>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // blocks that share a row tile (same A rows) are adjacent in `slot` on one XCD
   const int NBLK = Kout / BN;
@@ -48,103 +105,111 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   const int n0 = nb * BN;
 
   // ---- DMA sources --------------------------------------------------------------
-  // A: wave-instruction q (0..13) covers rows 8q..8q+7; lane -> row 8q + lane/8, unit' lane%8
-  // wave w issues q = w, w+4, w+8, (w+12 if < 14)
-  const float* a_src[4];
+  // A piece q covers rows q*RPP .. q*RPP+RPP-1 (RPP = 16 at BK 32... 1 KiB / row bytes);
+  // lane -> (row, unit'); source unit = unit' ^ f(row).  Wave w issues pieces w, w+8, ...
+  const float* a_src[G::A_PER_WAVE];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int q = w + 4 * j;
-    const int row = 8 * q + (lane >> 3);
-    const int unit = (lane & 7) ^ ((row >> 1) & 7);
+  for (int j = 0; j < G::A_PER_WAVE; j++) {
+    const int q = w + NW * j;
+    const int row = q * G::ROWS_PER_PIECE + lane / G::UNITS;
+    const int unit = (lane % G::UNITS) ^ G::fa(row);
     long gr = m0 + row;
-    gr = gr < M ? gr : M - 1;  // clamp: padded rows read a valid row
+    gr = gr < M ? gr : M - 1;  // clamp: padded rows (and pieces past the tile) read a valid row
     a_src[j] = A + gr * Cin + unit * 4;
   }
-  // B: wave-instruction q (0..15) covers k rows 2q, 2q+1; lane -> k = 2q + lane/32, unit' lane%32
-  const float* b_src[4];
+  // B piece q covers k rows 2q, 2q+1; lane -> k = 2q + lane/32, unit' lane%32
+  const float* b_src[G::B_PER_WAVE];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int q = w + 4 * j;
+  for (int j = 0; j < G::B_PER_WAVE; j++) {
+    const int q = w + NW * j;
     const int k = 2 * q + (lane >> 5);
     const int unit = (lane & 31) ^ (((k >> 2) & 1) << 2);
     b_src[j] = B + (size_t)k * Kout + n0 + unit * 4;
   }
-  auto issue = [&](int stage, int kc) {
-    char* sb = smem + stage * STAGE;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int q = w + 4 * j;
-      if (q < A_WAVE_INSTR) dma16(a_src[j] + kc * BK, sb + q * 1024);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int q = w + 4 * j;
-      dma16(b_src[j] + (size_t)kc * BK * Kout, sb + A_BYTES + q * 1024);
+  auto issue_piece = [&](int stage, int kc, int p) {  // p = 0 .. A_PER_WAVE + B_PER_WAVE - 1
+    char* sb = smem + stage * G::STAGE;
+    if (p < G::A_PER_WAVE) {
+      const int q = w + NW * p;
+      if (q < G::A_PIECES) dma16(a_src[p] + kc * BK, sb + q * 1024);
+    } else {
+      const int j = p - G::A_PER_WAVE, q = w + NW * j;
+      dma16(b_src[j] + (size_t)kc * BK * Kout, sb + G::A_BYTES + q * 1024);
     }
   };
+  constexpr int PIECES = G::A_PER_WAVE + G::B_PER_WAVE;
 
   // ---- fragment addresses ---------------------------------------------------------
   const int r16 = lane & 15, h = lane >> 4;
-  const int a_sw = (r16 >> 1) & 7;
-  // A row rb*16 + r16, k sub-chunk s (16 wide), lane reads unit (4s + h) -> unit' = (4s+h)^a_sw
-  int a_off[2];
+  // A row rb*16 + r16, sub-chunk s: unit 4s + h, stored at unit' = (4s + h) ^ f(row); f only
+  // depends on r16 for both BK (16 rows = a whole number of f periods)
+  int a_off[G::S];
 #pragma unroll
-  for (int s = 0; s < 2; s++) a_off[s] = r16 * 128 + (((4 * s + h) ^ a_sw) << 4);
-  // B element (k = 16s + 4h + j, col = 32w + 16cb + r16): float index k*128 + (col ^ 16*(h&1))
-  int b_off[2];
-#pragma unroll
-  for (int cb = 0; cb < 2; cb++)
-    b_off[cb] = A_BYTES + ((4 * h) * BN + ((32 * w + 16 * cb + r16) ^ ((h & 1) << 4))) * 4;
+  for (int s = 0; s < G::S; s++) a_off[s] = r16 * (BK * 4) + (((4 * s + h) ^ G::fa(r16)) << 4);
+  // B element (k = 16s + 4h + j, col = 16w + r16): float index k*128 + (col ^ 16*(h&1))
+  const int b_off = G::A_BYTES + ((4 * h) * BN + ((16 * w + r16) ^ ((h & 1) << 4))) * 4;
 
-  f32x4 acc[RB][2];
+  f32x4 acc[RB];
 #pragma unroll
-  for (int i = 0; i < RB; i++) {
-    acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
+  for (int i = 0; i < RB; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = Cin / BK;
-  issue(0, 0);
-  for (int it = 0; it < nk; ++it) {
+#pragma unroll
+  for (int p = 0; p < PIECES; p++) issue_piece(0, 0, p);
+
+  auto body = [&](auto par, int it) {
+    constexpr int PAR = decltype(par)::value;
     wait_vmem_all();
     __syncthreads();
-    if (it + 1 < nk) issue((it + 1) & 1, it + 1);
-    const char* st = smem + (it & 1) * STAGE;
+    const bool more = it + 1 < nk;
+    const char* st = smem + PAR * G::STAGE;
+    f32x4 a[G::T];
+    float b[G::S][4];
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      float b[2][4];
+    for (int j = 0; j < 4; j++) b[0][j] = *(const float*)(st + b_off + j * BN * 4);
+    a[0] = *(const f32x4*)(st + a_off[0]);
+    a[1] = *(const f32x4*)(st + 2048 * (BK / 32) + a_off[0]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          b[cb][j] = *(const float*)(st + b_off[cb] + (16 * s + j) * BN * 4);
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++) {
-        const f32x4 a = *(const f32x4*)(st + rb * 2048 + a_off[s]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[0][j], acc[rb][0], 0, 0, 0);
-          acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[1][j], acc[rb][1], 0, 0, 0);
-        }
+    for (int t = 0; t < G::T; t++) {
+      const int s = t / RB, rb = t % RB;
+      if (t + 2 < G::T) {
+        const int s2 = (t + 2) / RB, rb2 = (t + 2) % RB;
+        a[t + 2] = *(const f32x4*)(st + rb2 * 16 * BK * 4 + a_off[s2]);
       }
+      if (rb == 2 && s + 1 < G::S) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[s + 1][j] = *(const float*)(st + b_off + (16 * (s + 1) + j) * BN * 4);
+      }
+      // this wave's LDS-DMA pieces for the next stage, one per step from step 4 on
+      if (t >= 4 && t - 4 < PIECES) {
+        if (more) issue_piece(PAR ^ 1, it + 1, t - 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lds1(G::wait_count(t));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[s][j], acc[rb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  for (int it = 0; it < nk; it += 2) {
+    body(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < nk) body(std::integral_constant<int, 1>{}, it + 1);
   }
 
   // ---- epilogue: BN (+ReLU), C/D layout col = lane&15, row = 4*(lane>>4)+i ---------
+  const int col = n0 + 16 * w + r16;
+  const float sc = bnScale[col], bi = bnBias[col];
 #pragma unroll
-  for (int cb = 0; cb < 2; cb++) {
-    const int col = n0 + 32 * w + 16 * cb + r16;
-    const float sc = bnScale[col], bi = bnBias[col];
+  for (int rb = 0; rb < RB; rb++) {
 #pragma unroll
-    for (int rb = 0; rb < RB; rb++) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const long row = m0 + rb * 16 + 4 * h + i;
-        if (row < M) {
-          float y = sc * acc[rb][cb][i] + bi;
-          if (relu) y = fmaxf(y, 0.f);
-          Cout[row * Kout + col] = y;
-        }
+    for (int i = 0; i < 4; i++) {
+      const long row = m0 + rb * 16 + 4 * h + i;
+      if (row < M) {
+        float y = sc * acc[rb][i] + bi;
+        if (relu) y = fmaxf(y, 0.f);
+        Cout[row * Kout + col] = y;
       }
     }
   }
@@ -172,23 +237,40 @@ __global__ void conv1x1_direct_kernel(const float* __restrict__ A, const float* 
 
 using namespace wino;
 
+template <int BK>
+static int launch_1x1(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                      float* C, long M, int Cin, int Kout, int relu, int nMB, hipStream_t s) {
+  using G = Cfg<BK>;
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  WINO_HIP(hipGetDevice(&dev));
+  if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
+    WINO_HIP(hipFuncSetAttribute((const void*)conv1x1_bn_kernel<BK>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    attr_done.fetch_or(1ull << (dev & 63));
+  }
+  const int grid = 8 * (Kout / BN) * ((nMB + 7) / 8);
+  hipLaunchKernelGGL(conv1x1_bn_kernel<BK>, dim3(grid), dim3(NT), G::LDS_BYTES, s, A, B, bnBias,
+                     bnScale, C, M, Cin, Kout, relu, nMB);
+  return launch_status("conv1x1_bn_kernel");
+}
+
 extern "C" {
 
 int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const float* bnScale,
                     float* C, long M, int Cin, int Kout, int relu, wino_stream_t s) {
   if (!A || !B || !bnBias || !bnScale || !C) { set_error("NULL pointer"); return WINO_E_ARG; }
-  if (M < 1 || Cin <= 0 || Kout <= 0 || (Cin % BK) != 0 || (Kout % BN) != 0) {
-    set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% %d == 0, Kout %% %d == 0)",
-              M, Cin, Kout, BK, BN);
+  if (M < 1 || Cin <= 0 || Kout <= 0 || (Cin % 32) != 0 || (Kout % BN) != 0) {
+    set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% %d == 0)",
+              M, Cin, Kout, BN);
     return WINO_E_SHAPE;
   }
   const long nMBl = (M + BM - 1) / BM;
   if (nMBl > (1L << 24)) { set_error("M too large"); return WINO_E_SHAPE; }
   const int nMB = (int)nMBl;
-  const int grid = 8 * (Kout / BN) * ((nMB + 7) / 8);
-  hipLaunchKernelGGL(conv1x1_bn_kernel, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)s, A, B,
-                     bnBias, bnScale, C, M, Cin, Kout, relu, nMB);
-  return launch_status("conv1x1_bn_kernel");
+  if (Cin % 64 == 0)
+    return launch_1x1<64>(A, B, bnBias, bnScale, C, M, Cin, Kout, relu, nMB, (hipStream_t)s);
+  return launch_1x1<32>(A, B, bnBias, bnScale, C, M, Cin, Kout, relu, nMB, (hipStream_t)s);
 }
 
 int wino_conv1x1_direct(const float* A, const float* B, const float* bnBias,
