@@ -202,6 +202,7 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   };
 
   const int nchunks = C / BC;
+  if ((ABLATE & 256) && w >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the younger half
   unsigned long long stamp_c = 0, stamp_r = 0;
   if (ABLATE & 16) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime)
     stamp_c = __builtin_amdgcn_s_memtime();
@@ -296,10 +297,12 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       if (ABLATE & 4) {  // keep the operands live, skip the matrix pipe
         asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y));
       } else {
+        if (ABLATE & 128) __builtin_amdgcn_s_setprio(1);
         acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc[e][0], 0, 0, 0);
         acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc[e][1], 0, 0, 0);
         acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc[e][0], 0, 0, 0);
         acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc[e][1], 0, 0, 0);
+        if (ABLATE & 128) __builtin_amdgcn_s_setprio(0);
       }
       if (ABLATE & 32) continue;
       if (e >= 9 && e < 15) {  // points 2(e-9), 2(e-9)+1 < e have retired

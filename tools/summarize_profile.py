@@ -26,7 +26,7 @@ with open(os.path.join(dst, "kernel_stats.csv"), "w") as out:
             pass
         for r in csv.DictReader(open(f)):
             if any(h in r["Name"] for h in HOT):
-                name = r["Name"].split("(")[0].split("::")[-1]
+                name = next(h for h in HOT if h in r["Name"])
                 out.write(f'{layer},{name},{r["Calls"]},{float(r["AverageNs"]):.0f},{r["MinNs"]},{r["MaxNs"]},'
                           f'{bench.get("roofline", {}).get("kernel_us", "")}\n')
                 summary.setdefault(layer, {})["trace_avg_us"] = float(r["AverageNs"]) / 1e3
