@@ -335,69 +335,80 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     }
   }
 
-  // ---- epilogue: A^T m A, BN, ReLU, store (C/D layout: col = lane&15, row = 4*(lane>>4)+r)
-  float sc[2], bi[2];
-  int kcol[2];
-#pragma unroll
-  for (int cb = 0; cb < 2; cb++) {
-    kcol[cb] = kb * KB + wk * 32 + cb * 16 + t16;
-    sc[cb] = bnScale[kcol[cb]];
-    bi[cb] = bnBias[kcol[cb]];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int g = tb * TB + wt * 16 + 4 * h + r;
-    if (g >= totalTiles) continue;
-    const TileCoord tc = decode_tile(g);
-    float* img = out + (size_t)tc.n * WINO_HW * WINO_HW * K;
-    const int oy = 1 + 2 * tc.ty, ox = 1 + 2 * tc.tx;
+  // ---- epilogue: A^T m A, BN, ReLU (C/D layout: col = lane&15, row = 4*(lane>>4)+r), then the
+  // output tile goes through LDS so that it leaves as whole 256-byte pixel rows (dwordx4 per
+  // lane) instead of 64-byte fragments: the store tail is issue-bound, and this quarters the
+  // store instructions (32 -> 8 per wave).
+  // LDS image: Y[tile 0..63][px 0..3][k 0..63] floats, tile stride EP_TS (260: the +4 puts the
+  // two tile rows a 32-lane ds_write_b32 group touches on disjoint banks).
+  constexpr int EP_TS = 4 * KB + 4;
+  __syncthreads();  // every wave is done with the pipeline stages; no LDS-DMA is in flight
+  float* ylds = (float*)smem;
+  {
+    float sc[2], bi[2];
 #pragma unroll
     for (int cb = 0; cb < 2; cb++) {
-      float t0[4], t1[4];
+      const int kc = kb * KB + wk * 32 + cb * 16 + t16;
+      sc[cb] = bnScale[kc];
+      bi[cb] = bnBias[kc];
+    }
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float m0 = acc[0 * 4 + j][cb][r], m1 = acc[1 * 4 + j][cb][r];
-        const float m2 = acc[2 * 4 + j][cb][r], m3 = acc[3 * 4 + j][cb][r];
-        t0[j] = m0 + m1 + m2;
-        t1[j] = m1 - m2 - m3;
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++) {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float m0 = acc[0 * 4 + j][cb][r], m1 = acc[1 * 4 + j][cb][r];
+          const float m2 = acc[2 * 4 + j][cb][r], m3 = acc[3 * 4 + j][cb][r];
+          t0[j] = m0 + m1 + m2;
+          t1[j] = m1 - m2 - m3;
+        }
+        float y[4];
+        y[0] = t0[0] + t0[1] + t0[2];
+        y[1] = t0[1] - t0[2] - t0[3];
+        y[2] = t1[0] + t1[1] + t1[2];
+        y[3] = t1[1] - t1[2] - t1[3];
+        float* yl = ylds + (wt * 16 + 4 * h + r) * EP_TS + wk * 32 + cb * 16 + t16;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          float v1 = sc[cb] * y[p] + bi[cb];
+          if (relu) v1 = fmaxf(v1, 0.f);
+          yl[p * KB] = v1;
+        }
       }
-      float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
-      float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
-      y00 = sc[cb] * y00 + bi[cb];
-      y01 = sc[cb] * y01 + bi[cb];
-      y10 = sc[cb] * y10 + bi[cb];
-      y11 = sc[cb] * y11 + bi[cb];
-      if (relu) {
-        y00 = fmaxf(y00, 0.f);
-        y01 = fmaxf(y01, 0.f);
-        y10 = fmaxf(y10, 0.f);
-        y11 = fmaxf(y11, 0.f);
+    }
+  }
+  __syncthreads();
+  if (ABLATE & 512) return;  // price the store tail
+  // wave w stores tiles 8w .. 8w+7 of the block; one instruction = one tile = 4 pixel rows of
+  // 256 B: lane -> pixel (lane>>4) = (a,b), 16-byte chunk (lane&15) of the 64 out-channels
+  {
+    const int pxl = lane >> 4, chunk = lane & 15;
+    float* ocol = out + kb * KB + chunk * 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int tl = 8 * w + i;
+      const int g = tb * TB + tl;
+      if (g >= totalTiles) break;  // wave-uniform
+      const TileCoord tc = decode_tile(g);
+      const int oy = 1 + 2 * tc.ty, ox = 1 + 2 * tc.tx;
+      float* img = ocol + (size_t)tc.n * WINO_HW * WINO_HW * K;
+      const f32x4 val = *(const f32x4*)(ylds + tl * EP_TS + pxl * KB + chunk * 4);
+      *(f32x4*)(img + (size_t)((oy + (pxl >> 1)) * WINO_HW + ox + (pxl & 1)) * K) = val;
+      // zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:163,243): edge tiles
+      // also clear the ring pixels next to them; lane group 2 takes the corner.  All
+      // conditions on tc are wave-uniform.
+      if (tc.ty == 0 || tc.ty == 6) {
+        const int ry = tc.ty == 0 ? 0 : 15;
+        const bool corner = tc.tx == 0 || tc.tx == 6;
+        const int rx = pxl < 2 ? ox + pxl : (tc.tx == 0 ? 0 : 15);
+        if (pxl < 2 || (pxl == 2 && corner)) *(f32x4*)(img + (size_t)(ry * WINO_HW + rx) * K) = zero4;
       }
-      float* o = img + kcol[cb];
-      o[((oy)*WINO_HW + ox) * K] = y00;
-      o[((oy)*WINO_HW + ox + 1) * K] = y01;
-      o[((oy + 1) * WINO_HW + ox) * K] = y10;
-      o[((oy + 1) * WINO_HW + ox + 1) * K] = y11;
-      // zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:163,243)
-      if (tc.ty == 0) {
-        o[(ox)*K] = 0.f;
-        o[(ox + 1) * K] = 0.f;
-        if (tc.tx == 0) o[0] = 0.f;
-        if (tc.tx == 6) o[15 * K] = 0.f;
-      }
-      if (tc.ty == 6) {
-        o[(15 * WINO_HW + ox) * K] = 0.f;
-        o[(15 * WINO_HW + ox + 1) * K] = 0.f;
-        if (tc.tx == 0) o[(15 * WINO_HW) * K] = 0.f;
-        if (tc.tx == 6) o[(15 * WINO_HW + 15) * K] = 0.f;
-      }
-      if (tc.tx == 0) {
-        o[((oy)*WINO_HW) * K] = 0.f;
-        o[((oy + 1) * WINO_HW) * K] = 0.f;
-      }
-      if (tc.tx == 6) {
-        o[((oy)*WINO_HW + 15) * K] = 0.f;
-        o[((oy + 1) * WINO_HW + 15) * K] = 0.f;
+      if (tc.tx == 0 || tc.tx == 6) {
+        const int rx = tc.tx == 0 ? 0 : 15;
+        if (pxl < 2) *(f32x4*)(img + (size_t)((oy + pxl) * WINO_HW + rx) * K) = zero4;
       }
     }
   }

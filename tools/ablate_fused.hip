@@ -45,13 +45,12 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(U, h.data(), (size_t)16 * C * K * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b, h.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + K, K * 4, hipMemcpyHostToDevice));
   printf("C=K=%d   us per launch; WGs = 4*ceil(N*49/64) (K/64 k-blocks)\n", C);
-  printf("%6s %6s | %8s %8s %8s %8s | %8s %8s\n", "N", "WGs", "base", "prioMFMA", "prioYoung", "PF3", "noDMA", "noSync");
+  printf("%6s %6s | %8s %8s %8s %8s\n", "N", "WGs", "base", "noStores", "noDMA", "noDMA+noStores");
   for (int N : Ns) {
     const int wgs = (K / 64) * ((N * 49 + 63) / 64);
-    printf("%6d %6d | %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f\n", N, wgs,
-           run<0, 2, 8>(in, U, b, s, out, N, C, K, 20), run<128, 2, 8>(in, U, b, s, out, N, C, K, 20),
-           run<256, 2, 8>(in, U, b, s, out, N, C, K, 20), run<0, 3, 8>(in, U, b, s, out, N, C, K, 20),
-           run<3, 2, 8>(in, U, b, s, out, N, C, K, 20), run<8, 2, 8>(in, U, b, s, out, N, C, K, 20));
+    printf("%6d %6d | %8.1f %8.1f %8.1f %8.1f\n", N, wgs,
+           run<0, 2, 8>(in, U, b, s, out, N, C, K, 20), run<512, 2, 8>(in, U, b, s, out, N, C, K, 20),
+           run<3, 2, 8>(in, U, b, s, out, N, C, K, 20), run<515, 2, 8>(in, U, b, s, out, N, C, K, 20));
   }
   {  // in-kernel clock of the main loop (diagnostic build, ABLATE bit 16)
     const int N = 128;
