@@ -38,16 +38,21 @@ LAYERS = {
     "conv1x1_128_512": ("1x1", 128, 512, False),
     "conv1x1_1024_256": ("1x1", 1024, 256, True),
     "conv1x1_256_1024": ("1x1", 256, 1024, False),
+    "residual_block": ("block", 1024, 256, True),   # configs[4]: 1x1 1024->256, 3x3 256, 1x1 256->1024 + skip
 }
 BATCH = 128
 
 
 def algorithmic_flops(kind: str, N: int, C: int, K: int) -> float:
+    if kind == "block":   # C = outer width (1024), K = bottleneck width (256): 436.7 MFLOP / image
+        return 2.0 * N * 14 * 14 * (C * K + K * K * 9 + K * C)
     return 2.0 * N * 14 * 14 * K * C * (9 if kind == "3x3" else 1)
 
 
 def executed_mfma_flops(kind: str, N: int, C: int, K: int) -> float:
     """FLOPs the MFMA pipes execute: F(2x2,3x3) = 16 points x (N*49 tiles) x C x K x 2."""
+    if kind == "block":
+        return 2.0 * N * 14 * 14 * 2 * C * K + 2.0 * 16 * N * 49 * K * K
     return 2.0 * 16 * N * 49 * C * K if kind == "3x3" else algorithmic_flops(kind, N, C, K)
 
 
@@ -191,6 +196,14 @@ def main():
         U = pkg.filter_transform_f2(rnd(K, C, 3, 3))       # offline, outside the timed region
         out = torch.empty((N, 16, 16, K), device=dev)
         step = lambda: pkg.conv3x3_bn_relu(x, U, bias_v, scale_v, relu=relu, out=out)
+    elif kind == "block":
+        x = rnd(N, 14, 14, C)
+        w1, w3 = rnd(C, K, scale=4.0 / C ** 0.5), rnd(K, C, scale=4.0 / K ** 0.5)
+        U2 = pkg.filter_transform_f2(rnd(K, K, 3, 3, scale=4.0 / (9 * K) ** 0.5))
+        bn1, bn2, bn3 = (rnd(K), rnd(K) + 1.0), (rnd(K), rnd(K) + 1.0), (rnd(C), rnd(C) + 1.0)
+        out = torch.empty_like(x)
+        ws = torch.empty(pkg.lib().wino_residual_block_workspace_bytes(N, K) // 4, device=dev)
+        step = lambda: pkg.residual_block(x, w1, bn1, U2, bn2, w3, bn3, out=out, workspace=ws)
     else:
         A = rnd(N * 196, C, scale=40.0)
         B = rnd(C, K, scale=40.0)
@@ -237,17 +250,20 @@ def main():
     value = flops_rank * world * args.steps / elapsed / 1e12
     ach = flops_rank / (kernel_ms * 1e-3) / 1e12
     line = {
-        "metric": f"effective_tflops_{args.layer}_bn_relu_14x14_N128_fp32" if kind == "3x3"
+        "metric": f"effective_tflops_{args.layer}_bn_relu_14x14_N128_fp32" if kind != "1x1"
                   else f"effective_tflops_{args.layer}_bn_14x14_N128_fp32",
         "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
         "us_per_layer": round(elapsed / args.steps * 1e6, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{kind} conv {C}->{K} + folded BN" + (" + ReLU" if relu else "") +
-                               f", 14x14 (16x16 padded NHWC), N={N} per GPU, fp32",
-                   "algorithm": "fused Winograd F(2x2,3x3), one HIP launch" if kind == "3x3"
-                                else "fp32 MFMA GEMM, one HIP launch",
+        "config": {"workload": (f"{kind} conv {C}->{K} + folded BN" + (" + ReLU" if relu else "") +
+                                f", 14x14 (16x16 padded NHWC), N={N} per GPU, fp32") if kind != "block" else
+                               f"ResNet bottleneck 1x1 {C}->{K}, 3x3 {K}->{K}, 1x1 {K}->{C} + skip (BN+ReLU fused), "
+                               f"14x14, N={N} per GPU, fp32",
+                   "algorithm": {"3x3": "fused Winograd F(2x2,3x3), one HIP launch",
+                                 "1x1": "fp32 MFMA GEMM, one HIP launch",
+                                 "block": "3 HIP launches: MFMA GEMM, fused Winograd F(2x2,3x3), MFMA GEMM+skip"}[kind],
                    "global_batch": N * world, "parallelism": f"batch-split x{world}, no collective"},
         "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -258,7 +274,7 @@ def main():
                      "note": "achieved = algorithmic (direct-conv) FLOPs per launch / mean launch "
                              "duration from HIP events; Winograd executes 2.25x fewer MFMA FLOPs"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "block":
         line["cpu_baseline"] = cpu_baseline(kind, C, K, relu, args.cpu_images)
     if world > 1:
         import torch.distributed as dist

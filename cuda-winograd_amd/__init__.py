@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "wino_stream_destroy", "wino_stream_synchronize", "wino_event_create", "wino_event_destroy",
     "wino_event_record", "wino_event_elapsed_ms", "wino_filter_f2_elems",
     "wino_filter_transform_f2", "wino_filter_import_f4", "wino_conv3x3_bn_relu",
-    "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_direct", "wino_driver_set_batch",
+    "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_bn_ex", "wino_conv1x1_direct",
+    "wino_residual_block", "wino_residual_block_workspace_bytes", "wino_driver_set_batch",
     "wino_driver_set_gpus", "wino_driver_set_quiet", "wino_driver_get_batch",
     "wino_driver_get_gpus", "wino_driver_last_result",
     # reference entry points + helpers (Kernel*.h, util.h)
@@ -72,6 +73,10 @@ def lib() -> ctypes.CDLL:
     L.wino_conv3x3_direct.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv1x1_bn.argtypes = [fp, fp, fp, fp, fp, c_long, c_int, c_int, c_int, c_void_p]
     L.wino_conv1x1_direct.argtypes = [fp, fp, fp, fp, fp, c_long, c_int, c_int, c_int, c_void_p]
+    L.wino_conv1x1_bn_ex.argtypes = [fp, fp, fp, fp, fp, fp, c_long, c_int, c_int, c_int, c_void_p]
+    L.wino_residual_block_workspace_bytes.restype = c_size_t
+    L.wino_residual_block_workspace_bytes.argtypes = [c_int, c_int]
+    L.wino_residual_block.argtypes = [fp] * 11 + [c_int, c_int, c_int, fp, c_size_t, c_void_p]
     L.wino_device_count.argtypes = [POINTER(c_int)]
     L.wino_driver_last_result.argtypes = [POINTER(DriverResult)]
     L.wino_driver_set_batch.argtypes = [c_int]
@@ -176,6 +181,56 @@ def conv1x1_bn(A: torch.Tensor, B: torch.Tensor, bn_bias: torch.Tensor, bn_scale
     _check(lib().wino_conv1x1_bn(a.data_ptr(), bm.data_ptr(), b.data_ptr(), s.data_ptr(),
                                  out.data_ptr(), M, Cin, Kout, int(relu), _stream()),
            "wino_conv1x1_bn")
+    return out
+
+
+RELU, A_PADDED, C_PADDED, ADD_RESIDUAL = 1, 2, 4, 8  # WINO_* flag bits of wino_conv1x1_bn_ex
+
+
+def conv1x1_bn_ex(A, B, bn_bias, bn_scale, flags: int, residual=None, out=None) -> torch.Tensor:
+    """Chaining form of the 1x1 layer: A and/or C may be the padded [N][16][16][.] tensors of the
+    3x3 layer (flags A_PADDED / C_PADDED), a residual [M][Kout] may be added before the ReLU."""
+    a, bm = _dev(A, "A"), _dev(B, "B")
+    b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
+    Cin, Kout = int(bm.shape[0]), int(bm.shape[1])
+    if flags & A_PADDED:
+        if a.dim() != 4 or tuple(a.shape[1:]) != (16, 16, Cin):
+            raise WinoError("A_PADDED: A must be [N][16][16][Cin]")
+        M = int(a.shape[0]) * 196
+    else:
+        a = a.reshape(-1, Cin)
+        M = int(a.shape[0])
+    r = _dev(residual, "residual") if residual is not None else None
+    if flags & C_PADDED:
+        shape = (M // 196, 16, 16, Kout)
+    else:
+        shape = (M, Kout)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=a.device)
+    _check(lib().wino_conv1x1_bn_ex(a.data_ptr(), bm.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                    r.data_ptr() if r is not None else None, out.data_ptr(),
+                                    M, Cin, Kout, int(flags), _stream()), "wino_conv1x1_bn_ex")
+    return out
+
+
+def residual_block(x, w1, bn1, U2, bn2, w3, bn3, out=None, workspace=None) -> torch.Tensor:
+    """ResNet bottleneck of the 14x14 stage: x [N][14][14][C4] -> same shape.  bnX = (bias, scale)
+    folded BN vectors; w1 [C4][Cm], w3 [Cm][C4]; U2 from filter_transform_f2 (Cm -> Cm)."""
+    x = _dev(x, "x")
+    N, C4 = int(x.shape[0]), int(x.shape[-1])
+    w1, w3, U2 = _dev(w1, "w1"), _dev(w3, "w3"), _dev(U2, "U2")
+    Cm = int(w1.shape[1])
+    vecs = [_dev(v, "bn") for pair in (bn1, bn2, bn3) for v in pair]
+    need = lib().wino_residual_block_workspace_bytes(N, Cm)
+    if workspace is None:
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().wino_residual_block(x.data_ptr(), w1.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
+                                     U2.data_ptr(), vecs[2].data_ptr(), vecs[3].data_ptr(),
+                                     w3.data_ptr(), vecs[4].data_ptr(), vecs[5].data_ptr(),
+                                     out.data_ptr(), N, C4, Cm, workspace.data_ptr(),
+                                     workspace.numel() * 4, _stream()), "wino_residual_block")
     return out
 
 

@@ -51,6 +51,13 @@ __device__ __forceinline__ void wait_lds1(int n) {
   }
 }
 
+// logical pixel row m = n*196 + y*14 + x  ->  row of the padded [N][16][16][.] tensor
+__device__ __forceinline__ long padded_row(long m) {
+  const long n = m / (WINO_PQ * WINO_PQ);
+  const int rem = (int)(m - n * (WINO_PQ * WINO_PQ));
+  return n * (WINO_HW * WINO_HW) + (rem / WINO_PQ + 1) * WINO_HW + rem % WINO_PQ + 1;
+}
+
 template <int BK>
 struct Cfg {
   static constexpr int S = BK / 16;                 // 16-wide k sub-chunks per stage
@@ -88,8 +95,11 @@ template <int BK>
 __global__ void __launch_bounds__(NT, 2)
 conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                   const float* __restrict__ bnBias, const float* __restrict__ bnScale,
-                  float* __restrict__ Cout, long M, int Cin, int Kout, int relu, int nMB) {
+                  const float* __restrict__ R, float* __restrict__ Cout, long M, int Cin, int Kout,
+                  int flags, int nMB) {
   using G = Cfg<BK>;
+  const bool relu = flags & WINO_RELU, a_padded = flags & WINO_A_PADDED;
+  const bool c_padded = flags & WINO_C_PADDED, add_res = flags & WINO_ADD_RESIDUAL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // blocks that share a row tile (same A rows) are adjacent in `slot` on one XCD
   const int NBLK = Kout / BN;
@@ -115,6 +125,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     const int unit = (lane % G::UNITS) ^ G::fa(row);
     long gr = m0 + row;
     gr = gr < M ? gr : M - 1;  // clamp: padded rows (and pieces past the tile) read a valid row
+    if (a_padded) gr = padded_row(gr);
     a_src[j] = A + gr * Cin + unit * 4;
   }
   // B piece q covers k rows 2q, 2q+1; lane -> k = 2q + lane/32, unit' lane%32
@@ -198,7 +209,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     if (it + 1 < nk) body(std::integral_constant<int, 1>{}, it + 1);
   }
 
-  // ---- epilogue: BN (+ReLU), C/D layout col = lane&15, row = 4*(lane>>4)+i ---------
+  // ---- epilogue: BN (+residual) (+ReLU), C/D layout col = lane&15, row = 4*(lane>>4)+i ----
   const int col = n0 + 16 * w + r16;
   const float sc = bnScale[col], bi = bnBias[col];
 #pragma unroll
@@ -208,8 +219,24 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       const long row = m0 + rb * 16 + 4 * h + i;
       if (row < M) {
         float y = sc * acc[rb][i] + bi;
+        if (add_res) y += R[row * Kout + col];
         if (relu) y = fmaxf(y, 0.f);
-        Cout[row * Kout + col] = y;
+        if (!c_padded) {
+          Cout[row * Kout + col] = y;
+        } else {
+          // row = pixel (n, py-1, px-1) of the 14x14 map -> interior of [N][16][16][Kout];
+          // edge pixels also clear the ring pixels next to them (the 3x3 layer's padding)
+          const long n = row / (WINO_PQ * WINO_PQ);
+          const int rem = (int)(row - n * (WINO_PQ * WINO_PQ));
+          const int py = rem / WINO_PQ + 1, px = rem % WINO_PQ + 1;
+          float* img = Cout + (size_t)n * WINO_HW * WINO_HW * Kout + col;
+          img[(size_t)(py * WINO_HW + px) * Kout] = y;
+          const int ry = py == 1 ? 0 : (py == WINO_PQ ? WINO_HW - 1 : -1);
+          const int rx = px == 1 ? 0 : (px == WINO_PQ ? WINO_HW - 1 : -1);
+          if (ry >= 0) img[(size_t)(ry * WINO_HW + px) * Kout] = 0.f;
+          if (rx >= 0) img[(size_t)(py * WINO_HW + rx) * Kout] = 0.f;
+          if (ry >= 0 && rx >= 0) img[(size_t)(ry * WINO_HW + rx) * Kout] = 0.f;
+        }
       }
     }
   }
@@ -239,7 +266,8 @@ using namespace wino;
 
 template <int BK>
 static int launch_1x1(const float* A, const float* B, const float* bnBias, const float* bnScale,
-                      float* C, long M, int Cin, int Kout, int relu, int nMB, hipStream_t s) {
+                      const float* R, float* C, long M, int Cin, int Kout, int flags, int nMB,
+                      hipStream_t s) {
   using G = Cfg<BK>;
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
@@ -251,26 +279,65 @@ static int launch_1x1(const float* A, const float* B, const float* bnBias, const
   }
   const int grid = 8 * (Kout / BN) * ((nMB + 7) / 8);
   hipLaunchKernelGGL(conv1x1_bn_kernel<BK>, dim3(grid), dim3(NT), G::LDS_BYTES, s, A, B, bnBias,
-                     bnScale, C, M, Cin, Kout, relu, nMB);
+                     bnScale, R, C, M, Cin, Kout, flags, nMB);
   return launch_status("conv1x1_bn_kernel");
 }
 
 extern "C" {
 
-int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const float* bnScale,
-                    float* C, long M, int Cin, int Kout, int relu, wino_stream_t s) {
+int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                       const float* residual, float* C, long M, int Cin, int Kout, int flags,
+                       wino_stream_t s) {
   if (!A || !B || !bnBias || !bnScale || !C) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if ((flags & WINO_ADD_RESIDUAL) && !residual) { set_error("WINO_ADD_RESIDUAL without residual"); return WINO_E_ARG; }
+  if (flags & ~(WINO_RELU | WINO_A_PADDED | WINO_C_PADDED | WINO_ADD_RESIDUAL)) { set_error("unknown flag bits 0x%x", flags); return WINO_E_ARG; }
   if (M < 1 || Cin <= 0 || Kout <= 0 || (Cin % 32) != 0 || (Kout % BN) != 0) {
     set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% %d == 0)",
               M, Cin, Kout, BN);
+    return WINO_E_SHAPE;
+  }
+  if ((flags & (WINO_A_PADDED | WINO_C_PADDED)) && (M % (WINO_PQ * WINO_PQ)) != 0) {
+    set_error("padded layouts need M = N*196, got M=%ld", M);
     return WINO_E_SHAPE;
   }
   const long nMBl = (M + BM - 1) / BM;
   if (nMBl > (1L << 24)) { set_error("M too large"); return WINO_E_SHAPE; }
   const int nMB = (int)nMBl;
   if (Cin % 64 == 0)
-    return launch_1x1<64>(A, B, bnBias, bnScale, C, M, Cin, Kout, relu, nMB, (hipStream_t)s);
-  return launch_1x1<32>(A, B, bnBias, bnScale, C, M, Cin, Kout, relu, nMB, (hipStream_t)s);
+    return launch_1x1<64>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s);
+  return launch_1x1<32>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s);
+}
+
+int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                    float* C, long M, int Cin, int Kout, int relu, wino_stream_t s) {
+  return wino_conv1x1_bn_ex(A, B, bnBias, bnScale, NULL, C, M, Cin, Kout, relu ? WINO_RELU : 0, s);
+}
+
+// 1x1 (C4 -> Cm) + BN + ReLU  ->  3x3 (Cm -> Cm) + BN + ReLU  ->  1x1 (Cm -> C4) + BN + skip + ReLU.
+// Three launches on one stream; the two intermediates live in `workspace` in the padded
+// [N][16][16][Cm] layout the 3x3 kernel reads and writes, so no repacking pass exists.
+int wino_residual_block(const float* x, const float* w1, const float* bn1Bias, const float* bn1Scale,
+                        const float* U2, const float* bn2Bias, const float* bn2Scale,
+                        const float* w3, const float* bn3Bias, const float* bn3Scale, float* out,
+                        int N, int C4, int Cm, void* workspace, size_t workspace_bytes,
+                        wino_stream_t s) {
+  if (!workspace || workspace_bytes < wino_residual_block_workspace_bytes(N, Cm)) {
+    set_error("workspace too small: need %zu bytes", wino_residual_block_workspace_bytes(N, Cm));
+    return WINO_E_ARG;
+  }
+  float* t1 = (float*)workspace;
+  float* t2 = t1 + (size_t)N * WINO_HW * WINO_HW * Cm;
+  const long M = (long)N * WINO_PQ * WINO_PQ;
+  int rc = wino_conv1x1_bn_ex(x, w1, bn1Bias, bn1Scale, NULL, t1, M, C4, Cm, WINO_RELU | WINO_C_PADDED, s);
+  if (rc) return rc;
+  rc = wino_conv3x3_bn_relu(t1, U2, bn2Bias, bn2Scale, t2, N, Cm, Cm, 1, s);
+  if (rc) return rc;
+  return wino_conv1x1_bn_ex(t2, w3, bn3Bias, bn3Scale, x, out, M, Cm, C4,
+                            WINO_RELU | WINO_A_PADDED | WINO_ADD_RESIDUAL, s);
+}
+
+size_t wino_residual_block_workspace_bytes(int N, int Cm) {
+  return (size_t)2 * N * WINO_HW * WINO_HW * Cm * sizeof(float);
 }
 
 int wino_conv1x1_direct(const float* A, const float* B, const float* bnBias,

@@ -115,6 +115,35 @@ int wino_conv3x3_direct(const float* in, const float* w_kcrs, const float* bnBia
  * Constraints: Cin % 32 == 0, Kout % 128 == 0, M >= 1 (any M: the last row tile is ragged). */
 int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const float* bnScale,
                     float* C, long M, int Cin, int Kout, int relu, wino_stream_t s);
+/* Extended form used when layers are chained (the residual block):
+ *   WINO_RELU          ReLU after BN (+ residual)
+ *   WINO_A_PADDED      A's rows are the 14x14 interior pixels of a padded [N][16][16][Cin] tensor
+ *                      (what wino_conv3x3_bn_relu writes), M = N*196
+ *   WINO_C_PADDED      C's rows go to the interior of a padded [N][16][16][Kout] tensor and the ring
+ *                      is written as 0 (what wino_conv3x3_bn_relu reads), M = N*196
+ *   WINO_ADD_RESIDUAL  C = act(bnScale*(A.B) + bnBias + residual), residual [M][Kout] unpadded
+ * The reference has no such glue: its 1x1 layers are unpadded [196][C] and its 3x3 layers padded
+ * [16][16][C], and no kernel adds the skip connection. */
+#define WINO_RELU 1
+#define WINO_A_PADDED 2
+#define WINO_C_PADDED 4
+#define WINO_ADD_RESIDUAL 8
+int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                       const float* residual, float* C, long M, int Cin, int Kout, int flags,
+                       wino_stream_t s);
+
+/* ---- ResNet bottleneck block of the 14x14 stage (BASELINE.json configs[4]) ---------
+ * out = relu( bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x, w1))), U2))), w3)) + x )
+ * x, out [N][14][14][C4] (unpadded, = [N*196][C4]); w1 [C4][Cm], w3 [Cm][C4] (the reference's
+ * [Cin][Kout] 1x1 layout); U2 = packed F(2x2,3x3) filters of the Cm->Cm 3x3 layer; all BN folded.
+ * Three launches on `s`, intermediates in `workspace` (wino_residual_block_workspace_bytes). */
+size_t wino_residual_block_workspace_bytes(int N, int Cm);
+int wino_residual_block(const float* x, const float* w1, const float* bn1Bias, const float* bn1Scale,
+                        const float* U2, const float* bn2Bias, const float* bn2Scale,
+                        const float* w3, const float* bn3Bias, const float* bn3Scale, float* out,
+                        int N, int C4, int Cm, void* workspace, size_t workspace_bytes,
+                        wino_stream_t s);
+
 /* Independent comparator for the 1x1 layers: one thread per output, fp32 FMA loop. */
 int wino_conv1x1_direct(const float* A, const float* B, const float* bnBias,
                         const float* bnScale, float* C, long M, int Cin, int Kout, int relu,

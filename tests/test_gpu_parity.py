@@ -186,6 +186,57 @@ def test_one_by_one_full_size(name, pkg, O, torch_dev):
     assert O.rel_error(got, pkg.conv1x1_direct(At, Bt, bt, st, relu).cpu().numpy()) < TIGHT
 
 
+# ------------------------------------------------------------------ chaining
+def test_conv1x1_padded_in_out_and_residual(pkg, O, torch_dev):
+    torch, dev = torch_dev
+    rng = np.random.RandomState(21)
+    N, Cin, Kout = 3, 64, 128
+    A = (rng.rand(N, 14, 14, Cin) - 0.5).astype(np.float32)
+    B = (rng.rand(Cin, Kout) - 0.5).astype(np.float32)
+    s = (rng.rand(Kout) - 0.5).astype(np.float32)
+    b = (rng.rand(Kout) - 0.5).astype(np.float32)
+    R = (rng.rand(N * 196, Kout) - 0.5).astype(np.float32)
+    want = O.conv1x1_bn(A.reshape(-1, Cin), B, b, s, True)
+    # C_PADDED: result in the interior of [N][16][16][Kout], ring written as exact zeros
+    out = torch.full((N, 16, 16, Kout), float("nan"), device=dev)
+    pkg.conv1x1_bn_ex(_t(torch_dev, A), _t(torch_dev, B), _t(torch_dev, b), _t(torch_dev, s),
+                      pkg.RELU | pkg.C_PADDED, out=out)
+    got = out.cpu().numpy()
+    assert O.rel_error(got[:, 1:15, 1:15, :].reshape(-1, Kout), want) < TIGHT
+    assert (got[:, _ring(), :] == 0).all()
+    # A_PADDED: read the interior of a padded tensor whose ring holds garbage that must be ignored
+    Ap = rng.rand(N, 16, 16, Cin).astype(np.float32) * 100
+    Ap[:, 1:15, 1:15, :] = A
+    got2 = pkg.conv1x1_bn_ex(_t(torch_dev, Ap), _t(torch_dev, B), _t(torch_dev, b), _t(torch_dev, s),
+                             pkg.RELU | pkg.A_PADDED).cpu().numpy()
+    assert O.rel_error(got2, want) < TIGHT
+    # ADD_RESIDUAL before the ReLU
+    want3 = np.maximum(O.conv1x1_bn(A.reshape(-1, Cin), B, b, s, False) + R, 0)
+    got3 = pkg.conv1x1_bn_ex(_t(torch_dev, A), _t(torch_dev, B), _t(torch_dev, b), _t(torch_dev, s),
+                             pkg.RELU | pkg.ADD_RESIDUAL, residual=_t(torch_dev, R)).cpu().numpy()
+    assert O.rel_error(got3, want3) < TIGHT
+
+
+@pytest.mark.parametrize("N,C4,Cm", [(2, 256, 128), (5, 1024, 256)])
+def test_residual_block(N, C4, Cm, pkg, O, torch_dev):
+    """BASELINE configs[4]: 1x1 -> 3x3 -> 1x1 + skip, against the fp64 composition of the layer
+    oracles.  Weights are scaled so that activations stay O(1) through the block."""
+    rng = np.random.RandomState(33)
+    x = (rng.rand(N, 14, 14, C4) - 0.5).astype(np.float32)
+    w1 = ((rng.rand(C4, Cm) - 0.5) / np.sqrt(C4) * 4).astype(np.float32)
+    w2 = ((rng.rand(Cm, Cm, 3, 3) - 0.5) / np.sqrt(9 * Cm) * 4).astype(np.float32)
+    w3 = ((rng.rand(Cm, C4) - 0.5) / np.sqrt(Cm) * 4).astype(np.float32)
+    bn = [((rng.rand(c) - 0.5).astype(np.float32), (rng.rand(c) + 0.5).astype(np.float32)) for c in (Cm, Cm, C4)]
+    want = O.residual_block(x, w1, bn[0], w2, bn[1], w3, bn[2])
+    t = lambda a: _t(torch_dev, a)
+    U2 = pkg.filter_transform_f2(t(w2))
+    got = pkg.residual_block(t(x), t(w1), (t(bn[0][0]), t(bn[0][1])), U2, (t(bn[1][0]), t(bn[1][1])),
+                             t(w3), (t(bn[2][0]), t(bn[2][1]))).cpu().numpy()
+    assert got.shape == want.shape
+    assert O.rel_error(got, want) < TIGHT
+    assert (want > 0).mean() > 0.2  # the test exercises both sides of the final ReLU
+
+
 # ------------------------------------------------------------------ errors
 def test_bad_shapes_raise(pkg, torch_dev):
     torch, dev = torch_dev
