@@ -11,9 +11,9 @@
 //   wave (wt,wk) = 16 tiles x 32 out-channels x 16 points
 //                = 32 accumulator tiles of v_mfma_f32_16x16x4_f32 (128 acc VGPRs).
 //   per chunk  : LDS-DMA (global_load_lds_dwordx4) stages
-//                  raw[64 tiles][16 px][8 c]   (the 4x4 input patches, 32 KB)
-//                  U  [16 pts][64 k][8 c]      (pre-packed filter chunk, 32 KB)
-//                into one of two 64 KB LDS stages while the other one is consumed.
+//                  raw[64 tiles][16 px][8 c]   (the 4x4 input patches, 32 KB, 2 stages)
+//                  U  [16 pts][64 k][8 c]      (pre-packed filter chunk, 32 KB, 3 stages)
+//                two chunks ahead of the MFMAs (all 160 KB of the CU's LDS).
 //   A operand  : each lane reads its tile's 4x4 patch for 2 channels (16 x ds_read_b64),
 //                applies B^T d B in registers (32 VALU adds per channel) -> V[16 pts];
 //                no cross-lane traffic is needed because the MFMA A-fragment wants
@@ -36,10 +36,6 @@ namespace {
 
 using namespace fused;
 
-#ifndef WINO_PF
-#define WINO_PF 2    // filter-fragment prefetch distance (points)     } tuned on MI355X with
-#define WINO_DMA0 8  // first point-step that issues an LDS-DMA piece    } tools/ablate_fused
-#endif
 
 // Position (in floats, 0..7) inside the 8-channel group of the packed filter at which
 // channel `cl` (0..7) of out-channel `kl` (0..63 within the k-block) is stored: the
@@ -166,13 +162,13 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
   int dev = 0;
   WINO_HIP(hipGetDevice(&dev));
   if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
-    WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<0, WINO_PF, WINO_DMA0>),
+    WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<0>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done.fetch_or(1ull << (dev & 63));
   }
   const int nTB = (N * WINO_TILES + TB - 1) / TB;
   const int grid = 8 * (K / KB) * ((nTB + 7) / 8);
-  hipLaunchKernelGGL((wino_f2_fused_kernel<0, WINO_PF, WINO_DMA0>), dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s,
+  hipLaunchKernelGGL((wino_f2_fused_kernel<0>), dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s,
                      in, U, bnBias, bnScale, out, N, C, K, relu, nTB);
   return launch_status("wino_f2_fused_kernel");
 }

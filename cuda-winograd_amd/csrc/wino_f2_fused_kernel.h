@@ -1,8 +1,11 @@
 // The fused Winograd F(2x2,3x3) kernel, as a header so that the library
 // (wino_f2_fused.hip) and the ablation tool (tools/ablate_fused.hip) compile the same source.
-// ABLATE is a debug knob (0 = the product kernel): bit 0 skips the raw-patch DMA, bit 1 skips the
-// filter DMA, bit 2 skips the MFMAs, bit 3 skips the per-chunk wait+barrier.  Non-zero values
-// produce wrong results and exist only to price the parts of the kernel.
+//
+// ABLATE is a debug knob (0 = the product kernel); non-zero values produce wrong results and
+// exist only to price the parts of the kernel:
+//   1 skip the raw-patch LDS-DMA      2 skip the filter LDS-DMA      4 skip the MFMAs
+//   8 skip the per-chunk wait+barrier 16 stamp the main loop (in-kernel clock)
+//   32 skip the A-path reads+transform 64 skip the B-fragment reads  512 skip the output stores
 #pragma once
 #include "wino_common.h"
 
@@ -15,15 +18,14 @@ constexpr int TB = 64;                       // tiles per workgroup
 constexpr int KB = 64;                       // out-channels per workgroup
 constexpr int BC = 8;                        // in-channels per pipeline stage
 constexpr int NTHREADS = 512;
-constexpr int RAW_BYTES = TB * 16 * BC * 4;  // 32768
-constexpr int U_BYTES = 16 * KB * BC * 4;    // 32768
-constexpr int STAGE_BYTES = RAW_BYTES + U_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // 131072
+constexpr int RAW_BYTES = TB * 16 * BC * 4;  // 32768: one raw-patch stage
+constexpr int U_BYTES = 16 * KB * BC * 4;    // 32768: one filter stage
+constexpr int N_RSTAGE = 2, N_USTAGE = 3;
+constexpr int LDS_BYTES = N_RSTAGE * RAW_BYTES + N_USTAGE * U_BYTES;  // 163840 = all 160 KiB of the CU
 constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
+constexpr int PF = 2;                        // filter-fragment prefetch distance (points)
+constexpr int DMA0 = 8;                      // first point-step that issues an LDS-DMA piece
 
-// ---------------------------------------------------------------------------------
-// The fused kernel
-// ---------------------------------------------------------------------------------
 // s_waitcnt lgkmcnt(n) alone (vmcnt/expcnt fields at "no wait"); n folds to a literal once the
 // point loop is unrolled.
 __device__ __forceinline__ void wait_lds(int n) {
@@ -41,31 +43,21 @@ __device__ __forceinline__ void wait_lds(int n) {
     case 10: __builtin_amdgcn_s_waitcnt(0xCA7F); break;
     case 11: __builtin_amdgcn_s_waitcnt(0xCB7F); break;
     case 12: __builtin_amdgcn_s_waitcnt(0xCC7F); break;
-    case 13: __builtin_amdgcn_s_waitcnt(0xCD7F); break;
-    case 14: __builtin_amdgcn_s_waitcnt(0xCE7F); break;
     default: __builtin_amdgcn_s_waitcnt(0xCF7F); break;
   }
 }
-// LDS requests issued at the top of pinned step q of the point loop (see the kernel):
-// 2 filter-fragment reads while q + PF < 16, then 2 patch reads while q < 8.
-template <int PF> constexpr int lds_nb(int q) { return q + PF < 16 ? 2 : 0; }
+// LDS requests issued at the top of pinned step q of the point loop (see the kernel): always 2
+// filter-fragment reads (point q+2 of this chunk, or point q-14 of the NEXT chunk on steps
+// 14, 15), then 2 patch reads while q < 8.
 constexpr int lds_nr(int q) { return q < 8 ? 2 : 0; }
+constexpr int lds_n(int q) { return 2 + lds_nr(q); }
 // How many LDS requests are younger than the last one step e's consumers need: the filter
-// fragments of point e (requested at step e-PF, or in the pre-loop block for e < PF) and, on
-// steps 2,4,6,8, the patch pixels requested at steps e-2, e-1.
-template <int PF> constexpr int lds_wait_count(int e) {
-  int after = 0;
-  if (e < PF) {
-    after = 2 * (PF - 1 - e);
-    for (int q = 0; q <= e; q++) after += lds_nb<PF>(q) + lds_nr(q);
-  } else {
-    after = lds_nr(e - PF);
-    for (int q = e - PF + 1; q <= e; q++) after += lds_nb<PF>(q) + lds_nr(q);
-  }
-  if (e >= 2 && e <= 8 && (e & 1) == 0) {
-    const int t = lds_nb<PF>(e) + lds_nr(e);
-    after = t < after ? t : after;
-  }
+// fragments of point e (requested two steps earlier; for e < 2 before the barrier, which
+// drains lgkmcnt) and, on steps 2,4,6,8, the patch pixels requested at steps e-2, e-1.
+constexpr int lds_wait_count(int e) {
+  int after = 15;
+  if (e >= 2) after = lds_nr(e - 2) + lds_n(e - 1) + lds_n(e);
+  if (e >= 2 && e <= 8 && (e & 1) == 0) after = lds_n(e) < after ? lds_n(e) : after;
   return after > 15 ? 15 : after;
 }
 
@@ -81,7 +73,7 @@ __device__ __forceinline__ TileCoord decode_tile(int g) {
   return t;
 }
 
-template <int ABLATE, int PF, int DMA0 = 0>
+template <int ABLATE>
 __global__ void __launch_bounds__(NTHREADS, 2)
 wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
                      const float* __restrict__ bnBias, const float* __restrict__ bnScale,
@@ -127,11 +119,15 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   const float* u_src = Uq + (size_t)kb * U_CHUNK_FLOATS + w * 256 + lane * 4;
   const size_t u_chunk_stride = (size_t)KBLK * U_CHUNK_FLOATS;
 
-  // LDS map: [R0 32K][R1 32K][U0 32K][U1 32K]; R = raw 4x4 patches, U = filter chunk.
-  // The raw DMA runs ONE chunk ahead of the filter DMA: while the MFMAs of chunk `it` run
-  // (operands: V_it in registers, U_it in LDS), the wave reads raw_{it+1} from LDS and
-  // transforms it into V_{it+1} registers, so that the matrix pipe never waits for the input
-  // transform.
+  // LDS map: [R0 32K][R1 32K][U0 32K][U1 32K][U2 32K]; R = raw 4x4 patches, U = filter chunk.
+  // Both DMA streams run TWO chunks ahead of the MFMAs:
+  //  * raw_{i+1} is consumed one chunk early: while the MFMAs of chunk i run (operands: V_i in
+  //    registers, U_i in LDS) the wave reads raw_{i+1} from LDS and transforms it into V_{i+1},
+  //    in place over the V registers of points that have already retired, so the matrix pipe
+  //    never waits for the input transform (2 raw stages suffice);
+  //  * U_{i+1} is already visible during chunk i (3 filter stages), so the first filter
+  //    fragments of chunk i+1 are requested BEFORE the chunk barrier and the MFMAs resume right
+  //    after it instead of eating an LDS round trip.
   auto issue_raw1 = [&](int rstage, int chunk, int j) {  // one 1-KiB piece
     if (ABLATE & 1) return;
     dma16(raw_src[j] + chunk * BC, smem + rstage * RAW_BYTES + (8 * j + w) * 1024);
@@ -139,20 +135,7 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   auto issue_u1 = [&](int ustage, int chunk, int j) {
     if (ABLATE & 2) return;
     dma16(u_src + (size_t)chunk * u_chunk_stride + j * 2048,
-          smem + 2 * RAW_BYTES + ustage * U_BYTES + (8 * j + w) * 1024);
-  };
-  auto issue_raw = [&](int rstage, int chunk) {
-    if (ABLATE & 1) return;
-    char* sbase = smem + rstage * RAW_BYTES;
-#pragma unroll
-    for (int j = 0; j < 4; j++) dma16(raw_src[j] + chunk * BC, sbase + (8 * j + w) * 1024);
-  };
-  auto issue_u = [&](int ustage, int chunk) {
-    if (ABLATE & 2) return;
-    char* sbase = smem + 2 * RAW_BYTES + ustage * U_BYTES;
-    const float* us = u_src + (size_t)chunk * u_chunk_stride;
-#pragma unroll
-    for (int j = 0; j < 4; j++) dma16(us + j * 2048, sbase + (8 * j + w) * 1024);
+          smem + N_RSTAGE * RAW_BYTES + ustage * U_BYTES + (8 * j + w) * 1024);
   };
 
   // ---- fragment read addresses (loop invariant) ---------------------------------
@@ -161,21 +144,20 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   const int a_base = (wt * 16 + t16) * 512 + ((h ^ (((t16 >> 3) & 1) << 1)) << 3);
   const int a_sw = t16 & 7;
   // Fragment reads must stay plain ds_read_b64: that form banks on 64 dwords, for which the
-  // XOR layouts are conflict-free (SQ_LDS_BANK_CONFLICT = 0).  hipcc would fuse two reads off
-  // one base register into ds_read2_b64 / ds_read2st64_b64, which bank on 32 dwords (2-way
-  // conflicts here, half the bytes per clock).  Hiding how the bases relate (empty asm)
-  // prevents the fusion.
-  // (pixels px and px+8 share a base register, but are never read in the same pinned step.)
+  // XOR layouts are conflict-free.  hipcc would fuse two reads off one base register into
+  // ds_read2_b64 / ds_read2st64_b64, which bank on 32 dwords (2-way conflicts here, half the
+  // bytes per clock).  Hiding how the bases relate (empty asm) prevents the fusion; pixels px
+  // and px+8 share a base register but are never read in the same pinned step.
   int a_lo[8];
 #pragma unroll
   for (int p = 0; p < 8; p++) a_lo[p] = a_base + ((p ^ a_sw) << 5);
 #define A_OFF(px) (a_lo[(px) & 7] + (((px) >> 3) << 8))
-  // B: k_local = wk*32 + cb*16 + t16
+  // B: k_local = wk*32 + cb*16 + t16; byte offset inside a filter stage
   int b_base[2];
 #pragma unroll
   for (int cb = 0; cb < 2; cb++) {
     const int kl = wk * 32 + cb * 16 + t16;
-    b_base[cb] = 2 * RAW_BYTES + kl * 32 + ((h ^ (((kl >> 3) & 1) << 1)) << 3);
+    b_base[cb] = N_RSTAGE * RAW_BYTES + kl * 32 + ((h ^ (((kl >> 3) & 1) << 1)) << 3);
   }
   asm volatile("" : "+v"(b_base[1]));
 
@@ -202,22 +184,29 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   };
 
   const int nchunks = C / BC;
-  if ((ABLATE & 256) && w >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the younger half
   unsigned long long stamp_c = 0, stamp_r = 0;
   if (ABLATE & 16) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime)
     stamp_c = __builtin_amdgcn_s_memtime();
     stamp_r = __builtin_amdgcn_s_memrealtime();
   }
-  f32x2 v[16];  // V_it at the top of step `it`; rewritten in place with V_{it+1} as points retire
+  f32x2 v[16];       // V_it at the top of chunk `it`; rewritten in place with V_{it+1}
+  f32x2 bfn[2][2];   // filter fragments of points 0, 1 of the next chunk (requested pre-barrier)
 
-  // ---- prologue: chunk 0's patches and filters; V_0 computed un-pipelined -------------
-  issue_raw(0, 0);
-  issue_u(0, 0);
+  // ---- prologue: chunks 0 and 1 in flight; V_0 and chunk 0's first fragments un-pipelined --
+#pragma unroll
+  for (int j = 0; j < 4; j++) issue_raw1(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < 4; j++) issue_u1(0, 0, j);
   if (!(ABLATE & 8)) {
     wait_vmem_all();
     __syncthreads();
   }
-  if (nchunks > 1) issue_raw(1, 1);
+  if (nchunks > 1) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) issue_raw1(1, 1, j);
+#pragma unroll
+    for (int j = 0; j < 4; j++) issue_u1(1, 1, j);
+  }
   {
     f32x2 d[16], tmp[16];
 #pragma unroll
@@ -226,102 +215,108 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     for (int j = 0; j < 4; j++) tmp_col(tmp, d, j);
 #pragma unroll
     for (int e = 0; e < 16; e++) v_point(v, tmp, e);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      bfn[e][0] = *(const f32x2*)(smem + b_base[0] + e * 2048);
+      bfn[e][1] = *(const f32x2*)(smem + b_base[1] + e * 2048);
+    }
   }
 
   // One pipeline step = chunk `it`.  PAR = it & 1 is a compile-time constant (the loop is
-  // unrolled by two) so that every LDS stage offset folds into the ds_read immediate.
+  // unrolled by two) so that the raw-stage offsets fold into the ds_read immediates; the
+  // filter stage (it % 3) is a run-time offset added to the two fragment base registers.
   // The schedule inside is pinned with sched_barrier(0): left alone, hipcc sinks every
   // ds_read to just before its first use and the wave eats one LDS latency per point.
-  auto body = [&](auto par, int it) {
+  auto body = [&](auto par, int it, int us_cur, int us_nxt, int us_dma) {
     constexpr int PAR = decltype(par)::value;
     if (!(ABLATE & 8)) {
-      wait_vmem_all();   // my DMA pieces of raw_{it+1} and U_it have landed
+      wait_vmem_all();   // my DMA pieces of raw_{it+1} and U_{it+1} have landed
       __syncthreads();   // everyone's have; everyone is done with the stages refilled below
     }
     // The 8 LDS-DMA pieces this wave contributes per chunk (4 of raw_{it+2} into R[PAR], 4 of
-    // U_{it+1} into U[PAR^1]) are issued one per step in steps DMA0..DMA0+7 instead of in a
+    // U_{it+2} into U[(it+2)%3]) are issued one per step in steps DMA0..DMA0+7 instead of in a
     // burst here: an LDS-DMA instruction holds the wave's issue port for >100 cycles, and
     // spread out the SIMD's other wave covers that with its MFMAs.
-    const bool dma_raw = it + 2 < nchunks, dma_u = it + 1 < nchunks;
-    const char* ust = smem + PAR * U_BYTES;           // U_it
+    const bool dma_on = it + 2 < nchunks;
     const char* rst = smem + (PAR ^ 1) * RAW_BYTES;   // raw_{it+1}
+    const char* ucur0 = smem + b_base[0] + us_cur * U_BYTES;   // U_it
+    const char* ucur1 = smem + b_base[1] + us_cur * U_BYTES;
+    const char* unxt0 = smem + b_base[0] + us_nxt * U_BYTES;   // U_{it+1}
+    const char* unxt1 = smem + b_base[1] + us_nxt * U_BYTES;
 
     f32x2 bf[16][2];
-#pragma unroll
-    for (int e = 0; e < PF; e++) {
-      bf[e][0] = *(const f32x2*)(ust + b_base[0] + e * 2048);
-      bf[e][1] = *(const f32x2*)(ust + b_base[1] + e * 2048);
-    }
+    bf[0][0] = bfn[0][0]; bf[0][1] = bfn[0][1];
+    bf[1][0] = bfn[1][0]; bf[1][1] = bfn[1][1];
     f32x2 d[16], tmp[16];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 16; e++) {
       // -- top of the step: every LDS request of this step, before any MFMA.  Consumers sit
       //    at least one step later, so their waits are counted (lgkmcnt(N)), not drains.
-      if (e + PF < 16) {  // filter fragments of point e+PF
-        if (ABLATE & 64) {
-          bf[e + PF][0] = v[(e + 3) & 15];
-          bf[e + PF][1] = v[(e + 5) & 15];
-        } else {
-          bf[e + PF][0] = *(const f32x2*)(ust + b_base[0] + (e + PF) * 2048);
-          bf[e + PF][1] = *(const f32x2*)(ust + b_base[1] + (e + PF) * 2048);
-        }
+      if (ABLATE & 64) {
+        if (e + PF < 16) { bf[e + PF][0] = v[(e + 3) & 15]; bf[e + PF][1] = v[(e + 5) & 15]; }
+        else { bfn[e + PF - 16][0] = v[3]; bfn[e + PF - 16][1] = v[5]; }
+      } else if (e + PF < 16) {  // filter fragments of point e+PF
+        bf[e + PF][0] = *(const f32x2*)(ucur0 + (e + PF) * 2048);
+        bf[e + PF][1] = *(const f32x2*)(ucur1 + (e + PF) * 2048);
+      } else {                   // ... and of points 0, 1 of the next chunk
+        bfn[e + PF - 16][0] = *(const f32x2*)(unxt0 + (e + PF - 16) * 2048);
+        bfn[e + PF - 16][1] = *(const f32x2*)(unxt1 + (e + PF - 16) * 2048);
+      }
+      if (e >= DMA0 && e < DMA0 + 4) {
+        if (dma_on) issue_raw1(PAR, it + 2, e - DMA0);
+      } else if (e >= DMA0 + 4 && e < DMA0 + 8) {
+        if (dma_on) issue_u1(us_dma, it + 2, e - DMA0 - 4);
       }
       // next chunk's A operand rides along: steps 0-7 read the patch (two pixels of patch
       // column e>>1 per step), steps 2,4,6,8 form B^T d column by column, steps 9-15 form
       // (B^T d) B in place over the points that have retired.  (After the last chunk this
       // works on stale LDS; the result is never used -- cheaper than a branch per step.)
-      if (DMA0 >= 0) {
-        if (e >= DMA0 && e < DMA0 + 4) {
-          if (dma_raw) issue_raw1(PAR, it + 2, e - DMA0);
-        } else if (e >= DMA0 + 4 && e < DMA0 + 8) {
-          if (dma_u) issue_u1(PAR ^ 1, it + 1, e - DMA0 - 4);
-        }
-      } else {  // DMA0 < 0: the SIMD's two waves (w, w+4) take turns: steps 0-7 / 8-15
-        const int q = e & 7;
-        if ((e < 8) == (w < 4)) {
-          if (q < 4) { if (dma_raw) issue_raw1(PAR, it + 2, q); }
-          else       { if (dma_u) issue_u1(PAR ^ 1, it + 1, q - 4); }
-        }
-      }
       if (e < 8 && !(ABLATE & 32)) {
         const int j = e >> 1, i0 = (e & 1) * 2;
         d[(i0 + 0) * 4 + j] = *(const f32x2*)(rst + A_OFF((i0 + 0) * 4 + j));
         d[(i0 + 1) * 4 + j] = *(const f32x2*)(rst + A_OFF((i0 + 1) * 4 + j));
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!(ABLATE & 96)) wait_lds(lds_wait_count<PF>(e));
+      if (!(ABLATE & 96)) wait_lds(lds_wait_count(e));
       __builtin_amdgcn_sched_barrier(0);
       if (e >= 2 && e <= 8 && (e & 1) == 0 && !(ABLATE & 32)) tmp_col(tmp, d, (e >> 1) - 1);
       const f32x2 a = v[e], b0 = bf[e][0], b1 = bf[e][1];
       if (ABLATE & 4) {  // keep the operands live, skip the matrix pipe
         asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y));
       } else {
-        if (ABLATE & 128) __builtin_amdgcn_s_setprio(1);
         acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc[e][0], 0, 0, 0);
         acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc[e][1], 0, 0, 0);
         acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc[e][0], 0, 0, 0);
         acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc[e][1], 0, 0, 0);
-        if (ABLATE & 128) __builtin_amdgcn_s_setprio(0);
       }
-      if (ABLATE & 32) continue;
-      if (e >= 9 && e < 15) {  // points 2(e-9), 2(e-9)+1 < e have retired
-        v_point(v, tmp, 2 * (e - 9));
-        v_point(v, tmp, 2 * (e - 9) + 1);
-      }
-      if (e == 15) {
-        v_point(v, tmp, 12);
-        v_point(v, tmp, 13);
-        v_point(v, tmp, 14);
-        v_point(v, tmp, 15);
+      if (!(ABLATE & 32)) {
+        if (e >= 9 && e < 15) {  // points 2(e-9), 2(e-9)+1 < e have retired
+          v_point(v, tmp, 2 * (e - 9));
+          v_point(v, tmp, 2 * (e - 9) + 1);
+        }
+        if (e == 15) {
+          v_point(v, tmp, 12);
+          v_point(v, tmp, 13);
+          v_point(v, tmp, 14);
+          v_point(v, tmp, 15);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  for (int it = 0; it < nchunks; it += 2) {
-    body(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < nchunks) body(std::integral_constant<int, 1>{}, it + 1);
+  {
+    int us = 0;  // filter stage of chunk `it` (= it % 3)
+    auto next = [](int s) { return s == 2 ? 0 : s + 1; };
+    for (int it = 0; it < nchunks; it += 2) {
+      body(std::integral_constant<int, 0>{}, it, us, next(us), next(next(us)));
+      us = next(us);
+      if (it + 1 < nchunks) {
+        body(std::integral_constant<int, 1>{}, it + 1, us, next(us), next(next(us)));
+        us = next(us);
+      }
+    }
   }
 #undef A_OFF
   if (ABLATE & 16) {
@@ -337,8 +332,7 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
 
   // ---- epilogue: A^T m A, BN, ReLU (C/D layout: col = lane&15, row = 4*(lane>>4)+r), then the
   // output tile goes through LDS so that it leaves as whole 256-byte pixel rows (dwordx4 per
-  // lane) instead of 64-byte fragments: the store tail is issue-bound, and this quarters the
-  // store instructions (32 -> 8 per wave).
+  // lane) instead of 64-byte fragments.
   // LDS image: Y[tile 0..63][px 0..3][k 0..63] floats, tile stride EP_TS (260: the +4 puts the
   // two tile rows a 32-lane ds_write_b32 group touches on disjoint banks).
   constexpr int EP_TS = 4 * KB + 4;
@@ -413,7 +407,6 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     }
   }
 }
-
 
 }  // namespace fused
 }  // namespace wino

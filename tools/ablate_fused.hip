@@ -12,19 +12,19 @@ using namespace wino::fused;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int AB, int PF, int DMA0 = 0>
+template <int AB>
 float run(const float* in, const float* U, const float* b, const float* s, float* out, int N, int C, int K, int reps) {
-  CK(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<AB, PF, DMA0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  CK(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<AB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   const int nTB = (N * 49 + TB - 1) / TB;
   const int grid = 8 * (K / KB) * ((nTB + 7) / 8);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; i++)
-    hipLaunchKernelGGL((wino_f2_fused_kernel<AB, PF, DMA0>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB);
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < reps; i++)
-    hipLaunchKernelGGL((wino_f2_fused_kernel<AB, PF, DMA0>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB);
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -45,17 +45,19 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(U, h.data(), (size_t)16 * C * K * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b, h.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + K, K * 4, hipMemcpyHostToDevice));
   printf("C=K=%d   us per launch; WGs = 4*ceil(N*49/64) (K/64 k-blocks)\n", C);
-  printf("%6s %6s | %8s %8s %8s %8s\n", "N", "WGs", "base", "noStores", "noDMA", "noDMA+noStores");
+  printf("%6s %6s | %8s %8s %8s %8s %8s %8s %8s\n", "N", "WGs", "full", "noDMA", "noSync", "noAread", "noBread", "noStores", "noMFMA");
   for (int N : Ns) {
     const int wgs = (K / 64) * ((N * 49 + 63) / 64);
-    printf("%6d %6d | %8.1f %8.1f %8.1f %8.1f\n", N, wgs,
-           run<0, 2, 8>(in, U, b, s, out, N, C, K, 20), run<512, 2, 8>(in, U, b, s, out, N, C, K, 20),
-           run<3, 2, 8>(in, U, b, s, out, N, C, K, 20), run<515, 2, 8>(in, U, b, s, out, N, C, K, 20));
+    printf("%6d %6d | %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f\n", N, wgs,
+           run<0>(in, U, b, s, out, N, C, K, 20), run<3>(in, U, b, s, out, N, C, K, 20),
+           run<8>(in, U, b, s, out, N, C, K, 20), run<32>(in, U, b, s, out, N, C, K, 20),
+           run<64>(in, U, b, s, out, N, C, K, 20), run<512>(in, U, b, s, out, N, C, K, 20),
+           run<4>(in, U, b, s, out, N, C, K, 20));
   }
   {  // in-kernel clock of the main loop (diagnostic build, ABLATE bit 16)
     const int N = 128;
     const int nTB = (N * 49 + TB - 1) / TB, wgs = nTB * (K / KB);
-    run<16, 2>(in, U, b, s, out, N, C, K, 3);
+    run<16>(in, U, b, s, out, N, C, K, 3);
     std::vector<unsigned long long> st((size_t)wgs * 2);
     CK(hipMemcpy(st.data(), out + (size_t)N * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
     double cyc = 0, rt = 0, cmin = 1e30, cmax = 0;
