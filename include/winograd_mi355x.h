@@ -112,7 +112,7 @@ int wino_conv3x3_direct(const float* in, const float* w_kcrs, const float* bnBia
  * A [M][Cin] (M = N*196 pixels, HWC flat), B [Cin][Kout] row-major, C [M][Kout].
  * C = bnScale[k]*(A.B) + bnBias[k], ReLU if `relu`.  Argument order as the reference
  * kernels (A, B, bnBias, bnScale, C), Kernel128_one.cu:24.
- * Constraints: Cin % 32 == 0, Kout % 128 == 0, M >= 1 (any M: the last row tile is ragged). */
+ * Constraints: Cin % 32 == 0, Kout % 64 == 0, M >= 1 (any M: the last row tile is ragged). */
 int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const float* bnScale,
                     float* C, long M, int Cin, int Kout, int relu, wino_stream_t s);
 /* Extended form used when layers are chained (the residual block):
