@@ -27,14 +27,20 @@
 // LDS bank-conflict avoidance is done by XOR-permuting 16-byte units, applied on the DMA
 // *source* address for the raw patches (the LDS destination of an LDS-DMA is lane-linear)
 // and baked into the packed filter layout for U.
-#include "wino_f2_fused_kernel.h"
+#include "wino_f2_small_kernel.h"
 
 #include <atomic>
+#include <cstdlib>
+#include <cstring>
 
 namespace wino {
 namespace {
 
 using namespace fused;
+
+// Use the latency kernel while the throughput kernel would start at most this many workgroups
+// (tuned on MI355X).
+constexpr int SMALL_MAX_BIG_WGS = 64;
 
 
 // Position (in floats, 0..7) inside the 8-channel group of the packed filter at which
@@ -157,7 +163,21 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
   if (!in || !U || !bnBias || !bnScale || !out) { set_error("NULL pointer"); return WINO_E_ARG; }
   if (int rc = check_ck(C, K)) return rc;
   if (N < 1 || (long)N * WINO_TILES > (1L << 30)) { set_error("bad batch N=%d", N); return WINO_E_SHAPE; }
-  // raise the dynamic-LDS cap (128 KB of the CU's 160 KB) once per device
+  // Two kernels, same arithmetic: the throughput kernel (64 tiles x 64 out-channels per 8-wave
+  // workgroup) and, when that grid would leave most of the 256 CUs idle, the one-wave-per-
+  // workgroup latency kernel (16 tiles x 16 out-channels).  WINO_3X3_ALGO=big|small overrides.
+  const int nTB = (N * WINO_TILES + TB - 1) / TB;
+  static const char* algo_env = getenv("WINO_3X3_ALGO");
+  bool small = nTB * (K / KB) <= SMALL_MAX_BIG_WGS && (C % 16) == 0;
+  if (algo_env && !strcmp(algo_env, "big")) small = false;
+  if (algo_env && !strcmp(algo_env, "small")) small = (C % 16) == 0;
+  if (small) {
+    const int nT16 = (N * WINO_TILES + 15) / 16;
+    hipLaunchKernelGGL(wino_f2_small_kernel, dim3(nT16, K / 16), dim3(64), 0, (hipStream_t)s, in, U,
+                       bnBias, bnScale, out, N, C, K, relu);
+    return launch_status("wino_f2_small_kernel");
+  }
+  // raise the dynamic-LDS cap (all 160 KB of the CU) once per device
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
   WINO_HIP(hipGetDevice(&dev));
@@ -166,7 +186,6 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done.fetch_or(1ull << (dev & 63));
   }
-  const int nTB = (N * WINO_TILES + TB - 1) / TB;
   const int grid = 8 * (K / KB) * ((nTB + 7) / 8);
   hipLaunchKernelGGL((wino_f2_fused_kernel<0>), dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s,
                      in, U, bnBias, bnScale, out, N, C, K, relu, nTB);

@@ -109,10 +109,16 @@ def test_conv3x3_full_size_properties(pkg, O, torch_dev):
     assert O.rel_error(got, cmp_) < TIGHT
     # (c1) ring
     assert (got[:, _ring(), :] == 0).all()
-    # (c2) image n of the batch == the same image run alone, bit for bit
+    # (c2) images are independent: a sub-batch gives the same bits as the same images inside
+    # the full batch (both run the throughput kernel; tile blocks straddle image boundaries
+    # differently in the two runs) ...
+    sub = pkg.conv3x3_bn_relu(xt[37:101].contiguous(), U, bt, st).cpu().numpy()
+    assert np.array_equal(sub, got[37:101])
+    # ... and an image run alone (N = 1 takes the latency kernel, which contracts the channels in
+    # a different order) agrees to rounding
     for n in (0, 77, 127):
         alone = pkg.conv3x3_bn_relu(xt[n:n + 1].contiguous(), U, bt, st).cpu().numpy()
-        assert np.array_equal(alone[0], got[n])
+        assert O.rel_error(alone[0], got[n]) < TIGHT
     # (c3) linearity of conv+scale (no ReLU, zero bias): f(2x) == 2 f(x) exactly in fp32
     zb = torch.zeros_like(bt)
     f1 = pkg.conv3x3_bn_relu(xt[:4].contiguous(), U, zb, st, relu=False)
