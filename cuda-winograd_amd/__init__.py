@@ -47,7 +47,8 @@ class WinoError(RuntimeError):
 class DriverResult(ctypes.Structure):
     _fields_ = [("mine_us", ctypes.c_double), ("comparator_us", ctypes.c_double),
                 ("max_abs_err", ctypes.c_double), ("max_rel_err", ctypes.c_double),
-                ("error_cnt", c_long), ("flops", ctypes.c_double), ("N", c_int), ("gpus", c_int)]
+                ("error_cnt", c_long), ("flops", ctypes.c_double), ("N", c_int), ("gpus", c_int),
+                ("steady_us", ctypes.c_double)]
 
 
 _lib = None

@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
   }
 
   long sum_mine = 0, sum_cmp = 0;
-  double us_mine = 0, us_cmp = 0, worst_abs = 0, worst_rel = 0;
+  double us_mine = 0, us_cmp = 0, us_steady = 0, worst_abs = 0, worst_rel = 0;
   long worst_cnt = 0;
   wino_driver_result r;
   for (int i = 0; i < nTest; ++i) {
@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
       sum_cmp += packed & 0xFFFF;
       us_mine += r.mine_us;
       us_cmp += r.comparator_us;
+      us_steady += r.steady_us;
     }
   }
   const int counted = nTest - 2;
@@ -69,11 +70,15 @@ int main(int argc, char** argv) {
          (int)(sum_cmp / counted));
   us_mine /= counted;
   us_cmp /= counted;
+  us_steady /= counted;
   const double tflops = r.flops / (us_mine * 1e-6) / 1e12;
+  const double tflops_steady = r.flops / (us_steady * 1e-6) / 1e12;
   printf("{\"layer\": \"%s\", \"N\": %d, \"gpus\": %d, \"iters\": %d, \"mine_us\": %.1f, "
          "\"comparator_us\": %.1f, \"effective_tflops\": %.3f, \"frac_of_fp32_mfma_peak\": %.4f, "
+         "\"steady_us\": %.1f, \"steady_effective_tflops\": %.3f, \"steady_frac_of_fp32_mfma_peak\": %.4f, "
          "\"max_abs_err\": %.6g, \"max_rel_err\": %.3g, \"error_cnt_1e-5\": %ld}\n",
          LAYERS[mode].name, r.N, r.gpus, nTest, us_mine, us_cmp, tflops,
-         tflops / (MI355X_FP32_MFMA_PEAK_TFLOPS * r.gpus), worst_abs, worst_rel, worst_cnt);
+         tflops / (MI355X_FP32_MFMA_PEAK_TFLOPS * r.gpus), us_steady, tflops_steady,
+         tflops_steady / (MI355X_FP32_MFMA_PEAK_TFLOPS * r.gpus), worst_abs, worst_rel, worst_cnt);
   return 0;
 }
