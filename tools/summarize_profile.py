@@ -12,7 +12,13 @@ os.makedirs(dst, exist_ok=True)
 HOT = ("wino_f2_fused_kernel", "conv1x1_bn_kernel")
 
 def find(pattern):
-    return sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    """newest file per profiling directory (gpurun merges successive runs into the same tree)"""
+    best = {}
+    for f in glob.glob(os.path.join(src, pattern), recursive=True):
+        d = f.split(src + "/")[1].split("/")[0]
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
 
 summary = {}
 with open(os.path.join(dst, "kernel_stats.csv"), "w") as out:
@@ -54,6 +60,23 @@ for layer, s in summary.items():
         s["write_bytes"] = write
         traffic[layer] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_x2": fetch, "write_bytes": write,
                           "source": f"profiles/{tag}/summary.json"}
+# derived figures (per launch): matrix-pipe utilisation and HBM rate against the gfx950 peaks
+for layer, s in summary.items():
+    p = s.get("pmc", {})
+    t_us = s.get("trace_avg_us")
+    if not t_us:
+        continue
+    der = s.setdefault("derived", {})
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in p and "GRBM_GUI_ACTIVE" in p:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: /8 = shader cycles of the dispatch
+        cycles = p["GRBM_GUI_ACTIVE"] / 8.0
+        der["shader_clock_GHz_under_profiler"] = cycles / (t_us * 1e3)
+        der["mfma_busy_fraction_of_1024_SIMDs"] = p["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cycles)
+    if "hbm_bytes_per_launch" in s:
+        der["hbm_GBps"] = s["hbm_bytes_per_launch"] / (t_us * 1e-6) / 1e9
+        der["hbm_fraction_of_8TBps"] = der["hbm_GBps"] / 8000.0
+    if "TCC_HIT_sum" in p and "TCC_MISS_sum" in p:
+        der["l2_hit_rate"] = p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"])
 json.dump(summary, open(os.path.join(dst, "summary.json"), "w"), indent=1, sort_keys=True)
 if traffic:
     json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
