@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "wino_device_name", "wino_malloc", "wino_free", "wino_memset", "wino_memcpy_h2d",
     "wino_memcpy_d2h", "wino_memcpy_d2d", "wino_device_synchronize", "wino_stream_create",
     "wino_stream_destroy", "wino_stream_synchronize", "wino_event_create", "wino_event_destroy",
-    "wino_event_record", "wino_event_elapsed_ms", "wino_filter_f2_elems",
+    "wino_event_record", "wino_event_elapsed_ms", "wino_filter_f2_elems", "wino_filter_f2_index",
     "wino_filter_transform_f2", "wino_filter_import_f4", "wino_conv3x3_bn_relu",
     "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_bn_ex", "wino_conv1x1_direct",
     "wino_residual_block", "wino_residual_block_workspace_bytes", "wino_driver_set_batch",
@@ -68,6 +68,8 @@ def lib() -> ctypes.CDLL:
     L.wino_last_error_string.restype = c_char_p
     L.wino_filter_f2_elems.restype = c_size_t
     L.wino_filter_f2_elems.argtypes = [c_int, c_int]
+    L.wino_filter_f2_index.restype = c_long
+    L.wino_filter_f2_index.argtypes = [c_int] * 5
     L.wino_filter_transform_f2.argtypes = [fp, fp, c_int, c_int, c_void_p]
     L.wino_filter_import_f4.argtypes = [fp, fp, c_int, c_int, c_void_p]
     L.wino_conv3x3_bn_relu.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_void_p]

@@ -131,6 +131,12 @@ extern "C" {
 
 size_t wino_filter_f2_elems(int C, int K) { return (size_t)16 * C * K; }
 
+long wino_filter_f2_index(int C, int K, int e, int c, int k) {
+  if (C <= 0 || K <= 0 || (C % 8) || (K % 64) || e < 0 || e >= 16 || c < 0 || c >= C || k < 0 || k >= K)
+    return -1;
+  return (long)u_index(C, K, e, c, k);
+}
+
 static int check_ck(int C, int K) {
   if (C <= 0 || K <= 0 || (C % 8) != 0 || (K % 64) != 0) {
     set_error("unsupported channels C=%d K=%d (need C %% 8 == 0, K %% 64 == 0)", C, K);

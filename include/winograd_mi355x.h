@@ -82,6 +82,9 @@ int wino_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises o
  * K out-channels (= 16*C*K).  Its internal layout ([C/8][K/64][16][64][8], LDS-bank
  * swizzled) is private to the library. */
 size_t wino_filter_f2_elems(int C, int K);
+/* Position (in floats) of Winograd point e (0..15 = 4*row+col of G g G^T), in-channel c, out-channel k
+ * inside the packed buffer; -1 for out-of-range arguments.  Host-side, no GPU needed. */
+long wino_filter_f2_index(int C, int K, int e, int c, int k);
 /* w_kcrs: [K][C][3][3] (weight_NCHW_C_K.bin) -> U.  G g G^T evaluated in fp64, stored fp32. */
 int wino_filter_transform_f2(const float* w_kcrs, float* U, int C, int K, wino_stream_t s);
 /* u36: the reference's pre-transformed F(4x4,3x3) weights [36][C][K]

@@ -131,3 +131,20 @@ def test_shard_range_partitions(pkg):
             assert cover == list(range(N))
     with pytest.raises(ValueError):
         pkg.shard_range(8, 2, 2)
+
+
+def test_packed_filter_index_is_a_bijection(pkg):
+    """Every (point, in-channel, out-channel) owns exactly one slot of the packed F(2x2) buffer,
+    and the 8 channels x 64 out-channels x 16 points one workgroup stages per pipeline step are
+    contiguous (one 32 KB LDS-DMA slice)."""
+    L = pkg.lib()
+    C, K = 24, 128
+    idx = np.array([[[L.wino_filter_f2_index(C, K, e, c, k) for k in range(K)] for c in range(C)]
+                    for e in range(16)])
+    assert idx.min() == 0 and idx.max() == 16 * C * K - 1
+    assert np.unique(idx).size == idx.size
+    for chunk in range(C // 8):
+        for kb in range(K // 64):
+            sl = idx[:, 8 * chunk:8 * chunk + 8, 64 * kb:64 * kb + 64]
+            assert sl.max() - sl.min() == 16 * 8 * 64 - 1 and sl.min() % 8192 == 0
+    assert L.wino_filter_f2_index(C, K, 16, 0, 0) == -1 and L.wino_filter_f2_index(C, K, 0, C, 0) == -1

@@ -71,6 +71,24 @@ def test_reference_layers_match_golden(C, weights, data_dir, pkg, O, golden_outp
     assert max_err < 1e-4 and cnt < 0.01 * g.size
 
 
+def test_filter_transforms_match_oracle(data_dir, pkg, O, torch_dev):
+    """a12: the offline filter transform.  U = G g G^T (fp64 -> fp32) lands where
+    wino_filter_f2_index says, for both entry points (raw taps and the reference's F(4x4) file)."""
+    C = K = 128
+    w = load_bin(data_dir, f"weight_NCHW_{C}_{K}.bin").reshape(K, C, 3, 3)
+    u36 = load_bin(data_dir, f"weight_winograd_{C}_{K}.bin").reshape(36, C, K)
+    want = O.f2_filter_transform(w).astype(np.float32)                   # [16][C][K]
+    L = pkg.lib()
+    e, c, k = np.meshgrid(np.arange(16), np.arange(C), np.arange(K), indexing="ij")
+    # index of (e, c, k) -- vectorised from three probes per axis would hide bugs: call it for all
+    idx = np.fromiter((L.wino_filter_f2_index(C, K, int(a), int(b), int(d))
+                       for a, b, d in zip(e.ravel(), c.ravel(), k.ravel())), dtype=np.int64, count=e.size)
+    U1 = pkg.filter_transform_f2(_t(torch_dev, w)).cpu().numpy()
+    U2 = pkg.filter_import_f4(_t(torch_dev, u36)).cpu().numpy()
+    assert np.array_equal(U1[idx], want.ravel())
+    assert np.abs(U2[idx] - want.ravel()).max() < 2e-6       # taps recovered from fp32 F(4x4) weights
+
+
 # ------------------------------------------------------------------ batch sizes, ragged blocks
 @pytest.mark.parametrize("N,C,K", [(1, 8, 64), (2, 16, 64), (3, 128, 128), (5, 64, 192),
                                    (9, 256, 256), (17, 128, 256)])
