@@ -39,7 +39,14 @@ oracle: oracle/liboracle.so
 oracle/liboracle.so: oracle/cpu_conv.c
 	$(CC) -O3 -march=x86-64-v3 -fPIC -shared -std=gnu11 -o $@ $< -lpthread -lm
 
-clean:
-	rm -rf $(BUILD) $(LIB) Test oracle/liboracle.so
+# developer tools (ablation of the fused kernel, fp32 MFMA ceiling); not part of the library
+tools: tools/ablate_fused tools/mfma_peak
+tools/ablate_fused: tools/ablate_fused.hip $(wildcard $(CSRC)/*.h)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) $< -o $@
+tools/mfma_peak: tools/mfma_peak.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 
-.PHONY: all oracle clean
+clean:
+	rm -rf $(BUILD) $(LIB) Test oracle/liboracle.so tools/ablate_fused tools/mfma_peak
+
+.PHONY: all oracle tools clean

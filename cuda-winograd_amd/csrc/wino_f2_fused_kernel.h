@@ -189,6 +189,14 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     stamp_c = __builtin_amdgcn_s_memtime();
     stamp_r = __builtin_amdgcn_s_memrealtime();
   }
+  unsigned long long st_wait = 0, st_comp = 0, st_prev = 0;   // ABLATE & 2048: phase stamps
+  auto stamp = [&]() -> unsigned long long {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  };
   f32x2 v[16];       // V_it at the top of chunk `it`; rewritten in place with V_{it+1}
   f32x2 bfn[2][2];   // filter fragments of points 0, 1 of the next chunk (requested pre-barrier)
 
@@ -229,10 +237,12 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   // ds_read to just before its first use and the wave eats one LDS latency per point.
   auto body = [&](auto par, int it, int us_cur, int us_nxt, int us_dma) {
     constexpr int PAR = decltype(par)::value;
+    if (ABLATE & 2048) { const unsigned long long t = stamp(); if (it) st_comp += t - st_prev; st_prev = t; }
     if (!(ABLATE & 8)) {
       wait_vmem_all();   // my DMA pieces of raw_{it+1} and U_{it+1} have landed
       __syncthreads();   // everyone's have; everyone is done with the stages refilled below
     }
+    if (ABLATE & 2048) { const unsigned long long t = stamp(); st_wait += t - st_prev; st_prev = t; }
     // The 8 LDS-DMA pieces this wave contributes per chunk (4 of raw_{it+2} into R[PAR], 4 of
     // U_{it+2} into U[(it+2)%3]) are issued one per step in steps DMA0..DMA0+7 instead of in a
     // burst here: an LDS-DMA instruction holds the wave's issue port for >100 cycles, and
@@ -319,6 +329,15 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     }
   }
 #undef A_OFF
+  if (ABLATE & 2048) {
+    st_comp += stamp() - st_prev;
+    if (lane == 0) {
+      unsigned long long* dbg = (unsigned long long*)(out + (size_t)N * WINO_HW * WINO_HW * K) +
+                                ((size_t)(tb * KBLK + kb) * 8 + w) * 2;
+      dbg[0] = st_wait;
+      dbg[1] = st_comp;
+    }
+  }
   if (ABLATE & 16) {
     stamp_c = __builtin_amdgcn_s_memtime() - stamp_c;
     stamp_r = __builtin_amdgcn_s_memrealtime() - stamp_r;

@@ -65,5 +65,18 @@ int main(int argc, char** argv) {
     printf("main loop, N=128: in-kernel clock %.3f GHz; cycles per WG pass mean %.0f min %.0f max %.0f (= %.1f cycles per MFMA per SIMD)\n",
            cyc / rt * 0.1, cyc / wgs, cmin, cmax, cyc / wgs / (C / 8) / 128.0);
   }
+  {  // per-wave phase stamps (ABLATE bit 2048): barrier+DMA wait vs compute, in shader cycles
+    const int N = 128;
+    const int nTB = (N * 49 + TB - 1) / TB, wgs = nTB * (K / KB);
+    run<2048>(in, U, b, s, out, N, C, K, 2);
+    std::vector<unsigned long long> st((size_t)wgs * 16);
+    CK(hipMemcpy(st.data(), out + (size_t)N * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
+    double wsum[8] = {0}, csum[8] = {0};
+    for (int i = 0; i < wgs; i++) for (int w = 0; w < 8; w++) { wsum[w] += st[(i * 8 + w) * 2]; csum[w] += st[(i * 8 + w) * 2 + 1]; }
+    printf("per chunk (C/8 = %d chunks), mean over %d workgroups; stamps add overhead, read the SHARES:\n", C / 8, wgs);
+    for (int w = 0; w < 8; w++)
+      printf("  wave %d: wait(vmcnt+barrier) %7.0f cycles  compute %7.0f cycles  wait share %.1f%%\n", w,
+             wsum[w] / wgs / (C / 8), csum[w] / wgs / (C / 8), 100.0 * wsum[w] / (wsum[w] + csum[w]));
+  }
   return 0;
 }
