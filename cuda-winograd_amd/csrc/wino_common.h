@@ -39,6 +39,25 @@ __device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same 16-byte LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds):
+// per-lane 32-bit byte offset `voff` + wave-uniform byte offset `soff` (an SGPR), so that walking
+// a loop-uniform stride costs no VALU address arithmetic at all.  The buffer must be < 4 GiB.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)0, (short)0, 0, 0)) buffer_rsrc_t;
+__device__ __forceinline__ buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void dma16_buf(buffer_rsrc_t rsrc, unsigned voff, unsigned soff,
+                                          void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base,
+                                           16, voff, soff, 0, 0);
+}
+#else  // host pass: the kernels are only parsed, these builtins do not exist there
+typedef int buffer_rsrc_t;
+__device__ inline buffer_rsrc_t make_rsrc(const void*, unsigned) { return 0; }
+__device__ inline void dma16_buf(buffer_rsrc_t, unsigned, unsigned, void*) {}
+#endif
+
 __device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 }  // namespace wino

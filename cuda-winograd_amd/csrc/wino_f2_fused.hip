@@ -168,7 +168,11 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
                          wino_stream_t s) {
   if (!in || !U || !bnBias || !bnScale || !out) { set_error("NULL pointer"); return WINO_E_ARG; }
   if (int rc = check_ck(C, K)) return rc;
-  if (N < 1 || (long)N * WINO_TILES > (1L << 30)) { set_error("bad batch N=%d", N); return WINO_E_SHAPE; }
+  // the kernels address the input with 32-bit byte offsets
+  if (N < 1 || (size_t)N * WINO_HW * WINO_HW * (size_t)(C > K ? C : K) * sizeof(float) >= (1ull << 32)) {
+    set_error("bad batch N=%d (input/output must stay below 4 GiB)", N);
+    return WINO_E_SHAPE;
+  }
   // Two kernels, same arithmetic: the throughput kernel (64 tiles x 64 out-channels per 8-wave
   // workgroup) and, when that grid would leave most of the 256 CUs idle, the one-wave-per-
   // workgroup latency kernel (16 tiles x 16 out-channels).  WINO_3X3_ALGO=big|small overrides.

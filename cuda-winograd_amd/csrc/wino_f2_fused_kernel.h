@@ -100,7 +100,9 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   // raw stage layout: [tile 0..63][unit' 0..31] of 16 B; unit' = px'*2 + half'.
   // LDS unit (t, px', half') holds pixel px = px' ^ (t&7), channel half = half' ^ bit3(t).
   // wave-instruction q = 8*j + w (j = 0..3) covers tiles 2q, 2q+1.
-  const float* raw_src[4];
+  // (byte offsets from `in`, 32-bit: the DMA then uses the scalar-base + vector-offset address
+  //  form and advancing to the next chunk is a scalar add instead of a 64-bit VALU add per piece)
+  unsigned raw_off[4];
   {
     const int up = lane & 31;
     const int pxp = up >> 1, halfp = up & 1;
@@ -113,11 +115,15 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       g = g < totalTiles ? g : totalTiles - 1;  // clamp: padded rows read a valid tile
       const TileCoord tc = decode_tile(g);
       const int y = 2 * tc.ty + (px >> 2), x = 2 * tc.tx + (px & 3);
-      raw_src[j] = in + ((size_t)(tc.n * WINO_HW + y) * WINO_HW + x) * C + half * 4;
+      raw_off[j] = (unsigned)((((size_t)(tc.n * WINO_HW + y) * WINO_HW + x) * C + half * 4) * sizeof(float));
     }
   }
-  const float* u_src = Uq + (size_t)kb * U_CHUNK_FLOATS + w * 256 + lane * 4;
-  const size_t u_chunk_stride = (size_t)KBLK * U_CHUNK_FLOATS;
+  const unsigned u_off = lane * 16;
+  const unsigned u_soff0 = (unsigned)((kb * U_CHUNK_FLOATS + w * 256) * sizeof(float));
+  const unsigned u_chunk_stride = (unsigned)(KBLK * U_CHUNK_FLOATS * sizeof(float));
+  // buffer descriptors (wave-uniform): everything loop-variant goes into the scalar offset
+  const auto rsrc_in = make_rsrc(in, (unsigned)((size_t)N * WINO_HW * WINO_HW * C * sizeof(float)));
+  const auto rsrc_u = make_rsrc(Uq, (unsigned)((size_t)16 * C * K * sizeof(float)));
 
   // LDS map: [R0 32K][R1 32K][U0 32K][U1 32K][U2 32K]; R = raw 4x4 patches, U = filter chunk.
   // Both DMA streams run TWO chunks ahead of the MFMAs:
@@ -130,12 +136,13 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   //    after it instead of eating an LDS round trip.
   auto issue_raw1 = [&](int rstage, int chunk, int j) {  // one 1-KiB piece
     if (ABLATE & 1) return;
-    dma16(raw_src[j] + chunk * BC, smem + rstage * RAW_BYTES + (8 * j + w) * 1024);
+    dma16_buf(rsrc_in, raw_off[j], (unsigned)(chunk * (BC * sizeof(float))),
+              smem + rstage * RAW_BYTES + (8 * j + w) * 1024);
   };
   auto issue_u1 = [&](int ustage, int chunk, int j) {
     if (ABLATE & 2) return;
-    dma16(u_src + (size_t)chunk * u_chunk_stride + j * 2048,
-          smem + N_RSTAGE * RAW_BYTES + ustage * U_BYTES + (8 * j + w) * 1024);
+    dma16_buf(rsrc_u, u_off, u_soff0 + chunk * u_chunk_stride + j * 8192,
+              smem + N_RSTAGE * RAW_BYTES + ustage * U_BYTES + (8 * j + w) * 1024);
   };
 
   // ---- fragment read addresses (loop invariant) ---------------------------------
@@ -168,19 +175,35 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     acc[e][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  // B^T d B pieces (d, tmp, v are [row i][col j] = index 4i + j; Winograd point e = 4i + j)
-  auto tmp_col = [&](f32x2* tmp, const f32x2* d, int j) {  // B^T d, column j
-    tmp[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-    tmp[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-    tmp[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-    tmp[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+  // B^T d B pieces (d, tmp, v are [row i][col j] = index 4i + j; Winograd point e = 4i + j).
+  // Written per component: with WINO_SCALAR_XFORM the build passes -fno-slp-vectorize so that
+  // these stay v_add_f32/v_sub_f32 instead of v_pk_add_f32 (packed f32 VALU next to MFMAs
+  // measured slower than two plain ops on this chip).
+  struct P2 { float x, y; };  // two channels, deliberately NOT a vector type
+  auto sub2 = [](const P2& a, const P2& b) { P2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; };
+  auto add2 = [](const P2& a, const P2& b) { P2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; };
+  auto ld2 = [](const char* p) {
+    const f32x2 t = *(const f32x2*)p;
+    P2 r;
+    r.x = t.x;
+    r.y = t.y;
+#ifdef WINO_SCALAR_XFORM
+    asm volatile("" : "+v"(r.x), "+v"(r.y));  // opaque scalars: no <2 x float> re-vectorisation
+#endif
+    return r;
   };
-  auto v_point = [&](f32x2* v, const f32x2* tmp, int e) {  // (B^T d) B, point e
+  auto tmp_col = [&](P2* tmp, const P2* d, int j) {  // B^T d, column j
+    tmp[0 * 4 + j] = sub2(d[0 * 4 + j], d[2 * 4 + j]);
+    tmp[1 * 4 + j] = add2(d[1 * 4 + j], d[2 * 4 + j]);
+    tmp[2 * 4 + j] = sub2(d[2 * 4 + j], d[1 * 4 + j]);
+    tmp[3 * 4 + j] = sub2(d[1 * 4 + j], d[3 * 4 + j]);
+  };
+  auto v_point = [&](P2* v, const P2* tmp, int e) {  // (B^T d) B, point e
     const int i = e >> 2, j = e & 3;
-    if (j == 0) v[e] = tmp[i * 4 + 0] - tmp[i * 4 + 2];
-    if (j == 1) v[e] = tmp[i * 4 + 1] + tmp[i * 4 + 2];
-    if (j == 2) v[e] = tmp[i * 4 + 2] - tmp[i * 4 + 1];
-    if (j == 3) v[e] = tmp[i * 4 + 1] - tmp[i * 4 + 3];
+    if (j == 0) v[e] = sub2(tmp[i * 4 + 0], tmp[i * 4 + 2]);
+    if (j == 1) v[e] = add2(tmp[i * 4 + 1], tmp[i * 4 + 2]);
+    if (j == 2) v[e] = sub2(tmp[i * 4 + 2], tmp[i * 4 + 1]);
+    if (j == 3) v[e] = sub2(tmp[i * 4 + 1], tmp[i * 4 + 3]);
   };
 
   const int nchunks = C / BC;
@@ -197,7 +220,7 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     __builtin_amdgcn_sched_barrier(0);
     return t;
   };
-  f32x2 v[16];       // V_it at the top of chunk `it`; rewritten in place with V_{it+1}
+  P2 v[16];          // V_it at the top of chunk `it`; rewritten in place with V_{it+1}
   f32x2 bfn[2][2];   // filter fragments of points 0, 1 of the next chunk (requested pre-barrier)
 
   // ---- prologue: chunks 0 and 1 in flight; V_0 and chunk 0's first fragments un-pipelined --
@@ -216,9 +239,9 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     for (int j = 0; j < 4; j++) issue_u1(1, 1, j);
   }
   {
-    f32x2 d[16], tmp[16];
+    P2 d[16], tmp[16];
 #pragma unroll
-    for (int px = 0; px < 16; px++) d[px] = *(const f32x2*)(smem + A_OFF(px));
+    for (int px = 0; px < 16; px++) d[px] = ld2(smem + A_OFF(px));
 #pragma unroll
     for (int j = 0; j < 4; j++) tmp_col(tmp, d, j);
 #pragma unroll
@@ -257,15 +280,16 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     f32x2 bf[16][2];
     bf[0][0] = bfn[0][0]; bf[0][1] = bfn[0][1];
     bf[1][0] = bfn[1][0]; bf[1][1] = bfn[1][1];
-    f32x2 d[16], tmp[16];
+    P2 d[16], tmp[16];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 16; e++) {
       // -- top of the step: every LDS request of this step, before any MFMA.  Consumers sit
       //    at least one step later, so their waits are counted (lgkmcnt(N)), not drains.
       if (ABLATE & 64) {
-        if (e + PF < 16) { bf[e + PF][0] = v[(e + 3) & 15]; bf[e + PF][1] = v[(e + 5) & 15]; }
-        else { bfn[e + PF - 16][0] = v[3]; bfn[e + PF - 16][1] = v[5]; }
+        const f32x2 fake = {v[(e + 3) & 15].x, v[(e + 5) & 15].y};
+        if (e + PF < 16) { bf[e + PF][0] = fake; bf[e + PF][1] = fake; }
+        else { bfn[e + PF - 16][0] = fake; bfn[e + PF - 16][1] = fake; }
       } else if (e + PF < 16) {  // filter fragments of point e+PF
         bf[e + PF][0] = *(const f32x2*)(ucur0 + (e + PF) * 2048);
         bf[e + PF][1] = *(const f32x2*)(ucur1 + (e + PF) * 2048);
@@ -284,14 +308,15 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       // works on stale LDS; the result is never used -- cheaper than a branch per step.)
       if (e < 8 && !(ABLATE & 32)) {
         const int j = e >> 1, i0 = (e & 1) * 2;
-        d[(i0 + 0) * 4 + j] = *(const f32x2*)(rst + A_OFF((i0 + 0) * 4 + j));
-        d[(i0 + 1) * 4 + j] = *(const f32x2*)(rst + A_OFF((i0 + 1) * 4 + j));
+        d[(i0 + 0) * 4 + j] = ld2(rst + A_OFF((i0 + 0) * 4 + j));
+        d[(i0 + 1) * 4 + j] = ld2(rst + A_OFF((i0 + 1) * 4 + j));
       }
       __builtin_amdgcn_sched_barrier(0);
       if (!(ABLATE & 96)) wait_lds(lds_wait_count(e));
       __builtin_amdgcn_sched_barrier(0);
       if (e >= 2 && e <= 8 && (e & 1) == 0 && !(ABLATE & 32)) tmp_col(tmp, d, (e >> 1) - 1);
-      const f32x2 a = v[e], b0 = bf[e][0], b1 = bf[e][1];
+      const P2 a = v[e];
+      const f32x2 b0 = bf[e][0], b1 = bf[e][1];
       if (ABLATE & 4) {  // keep the operands live, skip the matrix pipe
         asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y));
       } else {
