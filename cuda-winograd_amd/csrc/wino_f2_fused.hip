@@ -40,7 +40,7 @@ using namespace fused;
 
 // Use the latency kernel while the throughput kernel would start at most this many workgroups
 // (tuned on MI355X).
-constexpr int SMALL_MAX_BIG_WGS = 64;
+constexpr int SMALL_MAX_BIG_WGS = 40;
 
 
 // Position (in floats, 0..7) inside the 8-channel group of the packed filter at which
@@ -183,7 +183,7 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
   if (algo_env && !strcmp(algo_env, "small")) small = (C % 16) == 0;
   if (small) {
     const int nT16 = (N * WINO_TILES + 15) / 16;
-    hipLaunchKernelGGL(wino_f2_small_kernel, dim3(nT16, K / 16), dim3(64), 0, (hipStream_t)s, in, U,
+    hipLaunchKernelGGL(wino_f2_small_kernel, dim3(nT16, K / 16), dim3(64 * SMALL_WAVES), 0, (hipStream_t)s, in, U,
                        bnBias, bnScale, out, N, C, K, relu);
     return launch_status("wino_f2_small_kernel");
   }

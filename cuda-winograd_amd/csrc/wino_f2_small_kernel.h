@@ -2,9 +2,10 @@
 // (the reference's own operating point is N = 1: `./Test 0`, `./Test 1`).
 //
 // At N = 1 a 256->256 layer has 49 tiles: the throughput kernel (64 tiles x 64 out-channels per
-// workgroup) would run on 4 of the 256 CUs.  Here a workgroup is ONE wave that owns 16 tiles x
+// workgroup) would run on 4 of the 256 CUs.  Here a workgroup owns 16 tiles x
 // 16 out-channels x all 16 Winograd points (64 accumulator VGPRs), so the same layer spreads
-// over 4 x 16 = 64 CUs and the C-loop is the only serial part.  There is no LDS and no barrier:
+// over 4 x 16 = 64 CUs; the C-loop, the only serial part, is split over the workgroup's 4 waves
+// (one per SIMD) whose partial accumulators are summed through LDS.  There is no LDS and no barrier:
 // the MFMA A/B fragment layouts ("one tile row / one out-channel column per lane, channel pair
 // by lane group") are read straight from global memory (16-byte loads), the next 16-channel
 // super-chunks are prefetched into registers while the current one is transformed and multiplied.
@@ -16,11 +17,15 @@
 namespace wino {
 namespace fused {
 
-__global__ void __launch_bounds__(64)
+constexpr int SMALL_WAVES = 4;  // waves per workgroup; each takes every 4th 16-channel super-chunk
+
+__global__ void __launch_bounds__(64 * SMALL_WAVES)
 wino_f2_small_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
                      const float* __restrict__ bnBias, const float* __restrict__ bnScale,
                      float* __restrict__ out, int N, int C, int K, int relu) {
-  const int lane = threadIdx.x;
+  __shared__ f32x4 red[SMALL_WAVES - 1][16][64];  // partial accumulators of waves 1..3 (48 KB)
+  const int lane = threadIdx.x & 63;
+  const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t16 = lane & 15, h = lane >> 4;
   const int tb16 = blockIdx.x, kq = blockIdx.y;
   const int totalTiles = N * WINO_TILES;
@@ -84,20 +89,32 @@ wino_f2_small_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   // loop is unrolled by two with named buffers and each refill is pinned (sched_barrier)
   // ahead of the compute it overlaps, or hipcc sinks the loads to their first use and the
   // kernel pays one full memory latency per chunk.
+  // wave q contracts super-chunks q, q+4, q+8, ...: the serial chain is 4x shorter, the four
+  // partial accumulators are summed through LDS at the end.
   f32x4 d0[16], b0[16], d1[16], b1[16];
-  load_chunk(0, d0, b0);
-  load_chunk(1, d1, b1);
+  load_chunk(q, d0, b0);
+  load_chunk(q + SMALL_WAVES, d1, b1);
   __builtin_amdgcn_sched_barrier(0);
-  for (int it = 0; it < nsuper; it += 2) {
+  for (int it = q; it < nsuper; it += 2 * SMALL_WAVES) {
     compute(d0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    load_chunk(it + 2, d0, b0);
+    load_chunk(it + 2 * SMALL_WAVES, d0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    if (it + 1 < nsuper) compute(d1, b1);
+    if (it + SMALL_WAVES < nsuper) compute(d1, b1);
     __builtin_amdgcn_sched_barrier(0);
-    load_chunk(it + 3, d1, b1);
+    load_chunk(it + 3 * SMALL_WAVES, d1, b1);
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (q > 0) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) red[q - 1][e][lane] = acc[e];
+  }
+  __syncthreads();
+  if (q > 0) return;
+#pragma unroll
+  for (int e = 0; e < 16; e++)
+#pragma unroll
+    for (int ww = 0; ww < SMALL_WAVES - 1; ww++) acc[e] += red[ww][e][lane];
 
   // epilogue (C/D layout: col = lane&15 = out-channel, row = 4*(lane>>4)+r = tile)
   const float sc = bnScale[k], bi = bnBias[k];
