@@ -150,6 +150,24 @@ def test_conv3x3_full_size_properties(pkg, O, torch_dev):
     assert np.abs(y.sum(axis=3) - ysum[..., 0]).max() < 1e-3 * np.abs(ysum).max()
 
 
+def test_conv3x3_is_deterministic_under_load(pkg, torch_dev):
+    """The fused kernel hands LDS stages between LDS-DMA writers and ds_read readers with one
+    barrier + vmcnt per chunk; a misplaced wait would show up as run-to-run differences (the
+    arithmetic itself has a fixed order).  30 back-to-back launches, alternating with a second
+    shape so that cache / LDS state differs between repeats, must agree bit for bit."""
+    torch, dev = torch_dev
+    g = torch.Generator(device="cpu").manual_seed(7)
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
+    x, w, s, b = mk(128, 16, 16, 256), mk(256, 256, 3, 3), mk(256), mk(256)
+    x2, w2, s2, b2 = mk(40, 16, 16, 128), mk(128, 128, 3, 3), mk(128), mk(128)
+    U, U2 = pkg.filter_transform_f2(w), pkg.filter_transform_f2(w2)
+    ref = pkg.conv3x3_bn_relu(x, U, b, s).clone()
+    ref2 = pkg.conv3x3_bn_relu(x2, U2, b2, s2).clone()
+    for _ in range(30):
+        assert torch.equal(pkg.conv3x3_bn_relu(x, U, b, s), ref)
+        assert torch.equal(pkg.conv3x3_bn_relu(x2, U2, b2, s2), ref2)
+
+
 def test_conv3x3_config2_128(pkg, O, torch_dev):
     """BASELINE configs[1]: 128->128, N=128, against the comparator + oracle sample."""
     rng = np.random.RandomState(43)
