@@ -183,9 +183,14 @@ def main():
     pkg = ge.load_package()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    rank, local_rank, world = dist_init("nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RCCL ("nccl") is the backend; WINO_BENCH_BACKEND=gloo rehearses the multi-rank control flow
+    # on a box with fewer GPUs than ranks (ranks then share devices round-robin)
+    backend = os.environ.get("WINO_BENCH_BACKEND", "nccl")
+    rank, local_rank, world = dist_init(backend)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else None
 
     kind, C, K, relu = LAYERS[args.layer]
     N = BATCH
@@ -222,7 +227,7 @@ def main():
         torch.cuda.synchronize(dev)
     if world > 1:
         import torch.distributed as dist
-        barrier = lambda: dist.barrier(device_ids=[local_rank])
+        barrier = (lambda: dist.barrier(device_ids=[dev_index])) if backend == "nccl" else dist.barrier
     else:
         barrier = lambda: None
 
@@ -250,7 +255,7 @@ def main():
     for _ in range(max(1, args.trials)):
         state["n"] = 0
         t = timed_steps(step_with_events, args.steps, 0, sync, barrier)
-        t = max_over_ranks(t, world, dev)
+        t = max_over_ranks(t, world, red_dev)
         if t < elapsed:
             elapsed, kernel_ms = t, ev0.elapsed_time(ev1) / args.steps
 
@@ -285,8 +290,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "block":
         line["cpu_baseline"] = cpu_baseline(kind, C, K, relu, args.cpu_images)
     if world > 1:
-        import torch.distributed as dist
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line), flush=True)
