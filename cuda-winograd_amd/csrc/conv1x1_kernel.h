@@ -1,0 +1,238 @@
+// The 1x1-conv GEMM kernel as a header, so that the library (conv1x1.hip) and the ablation tool
+// (tools/ablate_1x1.hip) compile the same source.  ABLATE (0 = product): 1 skip the A LDS-DMA,
+// 2 skip the B LDS-DMA, 4 skip the MFMAs, 8 skip the per-stage wait+barrier, 512 skip the stores.
+#pragma once
+#include "wino_common.h"
+
+#include <type_traits>
+
+namespace wino {
+namespace gemm1x1 {
+
+constexpr int BM = 112;
+constexpr int RB = BM / 16;  // 7 row blocks
+
+__device__ __forceinline__ void wait_lds1(int n) {
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0xC07F); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0xC17F); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0xC27F); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0xC37F); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0xC47F); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0xC57F); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0xC67F); break;
+    case 7: __builtin_amdgcn_s_waitcnt(0xC77F); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0xC87F); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0xC97F); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0xCA7F); break;
+    case 11: __builtin_amdgcn_s_waitcnt(0xCB7F); break;
+    case 12: __builtin_amdgcn_s_waitcnt(0xCC7F); break;
+    default: __builtin_amdgcn_s_waitcnt(0xCF7F); break;
+  }
+}
+
+// logical pixel row m = n*196 + y*14 + x  ->  row of the padded [N][16][16][.] tensor
+__device__ __forceinline__ long padded_row(long m) {
+  const long n = m / (WINO_PQ * WINO_PQ);
+  const int rem = (int)(m - n * (WINO_PQ * WINO_PQ));
+  return n * (WINO_HW * WINO_HW) + (rem / WINO_PQ + 1) * WINO_HW + rem % WINO_PQ + 1;
+}
+
+template <int BK, int NW>
+struct Cfg {
+  static constexpr int NT = 64 * NW;                // threads per workgroup
+  static constexpr int BN = 16 * NW;                // output columns per workgroup (one 16-col block per wave)
+  static constexpr int S = BK / 16;                 // 16-wide k sub-chunks per stage
+  static constexpr int T = S * RB;                  // pinned steps per stage (4 MFMAs each)
+  static constexpr int UNITS = BK / 4;              // 16-byte units per A row
+  static constexpr int A_BYTES = BM * BK * 4;
+  static constexpr int B_BYTES = BK * BN * 4;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int A_PIECES = A_BYTES / 1024;   // LDS-DMA wave-instructions per stage
+  static constexpr int B_PIECES = B_BYTES / 1024;
+  static constexpr int A_PER_WAVE = (A_PIECES + NW - 1) / NW;
+  static constexpr int B_PER_WAVE = B_PIECES / NW;
+  static constexpr int ROWS_PER_PIECE = 1024 / (BK * 4);
+  static constexpr int B_UNITS = BN / 4;            // 16-byte units per B row
+  static constexpr int B_ROWS_PER_PIECE = 1024 / (BN * 4);
+  static __device__ __forceinline__ int fa(int row) { return BK == 64 ? (row & 15) : ((row >> 1) & 7); }
+  // LDS requests at the top of step q: the A fragment of step q+2, then (on row block 2) the
+  // four B values of the next sub-chunk
+  static constexpr int nA(int q) { return q + 2 < T ? 1 : 0; }
+  static constexpr int nB(int q) { return (q % RB == 2 && q / RB + 1 < S) ? 4 : 0; }
+  // requests younger than the A fragment step t consumes
+  static constexpr int wait_count(int t) {
+    int after = 0;
+    if (t < 2) {
+      after = 1 - t;                                  // pre-loop block: B(0)x4, A(0), A(1)
+      for (int q = 0; q <= t; q++) after += nA(q) + nB(q);
+    } else {
+      after = nB(t - 2);
+      for (int q = t - 1; q <= t; q++) after += nA(q) + nB(q);
+    }
+    return after;
+  }
+};
+
+template <int BK, int NW, int ABLATE = 0>
+__global__ void __launch_bounds__(64 * NW, 2)
+conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                  const float* __restrict__ bnBias, const float* __restrict__ bnScale,
+                  const float* __restrict__ R, float* __restrict__ Cout, long M, int Cin, int Kout,
+                  int flags, int nMB) {
+  using G = Cfg<BK, NW>;
+  constexpr int BN = G::BN;
+  const bool relu = flags & WINO_RELU, a_padded = flags & WINO_A_PADDED;
+  const bool c_padded = flags & WINO_C_PADDED, add_res = flags & WINO_ADD_RESIDUAL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // blocks that share a row tile (same A rows) are adjacent in `slot` on one XCD
+  const int NBLK = Kout / BN;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int nb = slot % NBLK;
+  const int mb = (slot / NBLK) * 8 + xcd;
+  if (mb >= nMB) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long m0 = (long)mb * BM;
+  const int n0 = nb * BN;
+
+  // ---- DMA sources --------------------------------------------------------------
+  // A piece q covers rows q*RPP .. q*RPP+RPP-1 (RPP = 16 at BK 32... 1 KiB / row bytes);
+  // lane -> (row, unit'); source unit = unit' ^ f(row).  Wave w issues pieces w, w+8, ...
+  const float* a_src[G::A_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < G::A_PER_WAVE; j++) {
+    const int q = w + NW * j;
+    const int row = q * G::ROWS_PER_PIECE + lane / G::UNITS;
+    const int unit = (lane % G::UNITS) ^ G::fa(row);
+    long gr = m0 + row;
+    gr = gr < M ? gr : M - 1;  // clamp: padded rows (and pieces past the tile) read a valid row
+    if (a_padded) gr = padded_row(gr);
+    a_src[j] = A + gr * Cin + unit * 4;
+  }
+  // B piece q covers B_ROWS_PER_PIECE k rows; lane -> (k, unit'); source unit = unit' ^ 4*bit2(k)
+  const float* b_src[G::B_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < G::B_PER_WAVE; j++) {
+    const int q = w + NW * j;
+    const int k = G::B_ROWS_PER_PIECE * q + lane / G::B_UNITS;
+    const int unit = (lane % G::B_UNITS) ^ (((k >> 2) & 1) << 2);
+    b_src[j] = B + (size_t)k * Kout + n0 + unit * 4;
+  }
+  auto issue_piece = [&](int stage, int kc, int p) {  // p = 0 .. A_PER_WAVE + B_PER_WAVE - 1
+    char* sb = smem + stage * G::STAGE;
+    if (p < G::A_PER_WAVE) {
+      const int q = w + NW * p;
+      if (q < G::A_PIECES && !(ABLATE & 1)) dma16(a_src[p] + kc * BK, sb + q * 1024);
+    } else {
+      const int j = p - G::A_PER_WAVE, q = w + NW * j;
+      if (!(ABLATE & 2)) dma16(b_src[j] + (size_t)kc * BK * Kout, sb + G::A_BYTES + q * 1024);
+    }
+  };
+  constexpr int PIECES = G::A_PER_WAVE + G::B_PER_WAVE;
+
+  // ---- fragment addresses ---------------------------------------------------------
+  const int r16 = lane & 15, h = lane >> 4;
+  // A row rb*16 + r16, sub-chunk s: unit 4s + h, stored at unit' = (4s + h) ^ f(row); f only
+  // depends on r16 for both BK (16 rows = a whole number of f periods)
+  int a_off[G::S];
+#pragma unroll
+  for (int s = 0; s < G::S; s++) a_off[s] = r16 * (BK * 4) + (((4 * s + h) ^ G::fa(r16)) << 4);
+  // B element (k = 16s + 4h + j, col = 16w + r16): float index k*128 + (col ^ 16*(h&1))
+  const int b_off = G::A_BYTES + ((4 * h) * BN + ((16 * w + r16) ^ ((h & 1) << 4))) * 4;
+
+  f32x4 acc[RB];
+#pragma unroll
+  for (int i = 0; i < RB; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = Cin / BK;
+#pragma unroll
+  for (int p = 0; p < PIECES; p++) issue_piece(0, 0, p);
+
+  auto body = [&](auto par, int it) {
+    constexpr int PAR = decltype(par)::value;
+    if (!(ABLATE & 8)) {
+      wait_vmem_all();
+      __syncthreads();
+    }
+    const bool more = it + 1 < nk;
+    const char* st = smem + PAR * G::STAGE;
+    f32x4 a[G::T];
+    float b[G::S][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[0][j] = *(const float*)(st + b_off + j * BN * 4);
+    a[0] = *(const f32x4*)(st + a_off[0]);
+    a[1] = *(const f32x4*)(st + 2048 * (BK / 32) + a_off[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < G::T; t++) {
+      const int s = t / RB, rb = t % RB;
+      if (t + 2 < G::T) {
+        const int s2 = (t + 2) / RB, rb2 = (t + 2) % RB;
+        a[t + 2] = *(const f32x4*)(st + rb2 * 16 * BK * 4 + a_off[s2]);
+      }
+      if (rb == 2 && s + 1 < G::S) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[s + 1][j] = *(const float*)(st + b_off + (16 * (s + 1) + j) * BN * 4);
+      }
+      // this wave's LDS-DMA pieces for the next stage, one per step from step 4 on
+      if (t >= 4 && t - 4 < PIECES) {
+        if (more) issue_piece(PAR ^ 1, it + 1, t - 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lds1(G::wait_count(t));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (ABLATE & 4) asm volatile("" ::"v"(a[t][j]), "v"(b[s][j]));
+        else acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[s][j], acc[rb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int it = 0; it < nk; it += 2) {
+    body(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < nk) body(std::integral_constant<int, 1>{}, it + 1);
+  }
+
+  // ---- epilogue: BN (+residual) (+ReLU), C/D layout col = lane&15, row = 4*(lane>>4)+i ----
+  const int col = n0 + 16 * w + r16;
+  const float sc = bnScale[col], bi = bnBias[col];
+#pragma unroll
+  for (int rb = 0; rb < RB; rb++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const long row = m0 + rb * 16 + 4 * h + i;
+      if (row < M) {
+        float y = sc * acc[rb][i] + bi;
+        if (add_res) y += R[row * Kout + col];
+        if (relu) y = fmaxf(y, 0.f);
+        if (ABLATE & 512) {
+          asm volatile("" ::"v"(y));
+        } else if (!c_padded) {
+          Cout[row * Kout + col] = y;
+        } else {
+          // row = pixel (n, py-1, px-1) of the 14x14 map -> interior of [N][16][16][Kout];
+          // edge pixels also clear the ring pixels next to them (the 3x3 layer's padding)
+          const long n = row / (WINO_PQ * WINO_PQ);
+          const int rem = (int)(row - n * (WINO_PQ * WINO_PQ));
+          const int py = rem / WINO_PQ + 1, px = rem % WINO_PQ + 1;
+          float* img = Cout + (size_t)n * WINO_HW * WINO_HW * Kout + col;
+          img[(size_t)(py * WINO_HW + px) * Kout] = y;
+          const int ry = py == 1 ? 0 : (py == WINO_PQ ? WINO_HW - 1 : -1);
+          const int rx = px == 1 ? 0 : (px == WINO_PQ ? WINO_HW - 1 : -1);
+          if (ry >= 0) img[(size_t)(ry * WINO_HW + px) * Kout] = 0.f;
+          if (rx >= 0) img[(size_t)(py * WINO_HW + rx) * Kout] = 0.f;
+          if (ry >= 0 && rx >= 0) img[(size_t)(ry * WINO_HW + rx) * Kout] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+
+}  // namespace gemm1x1
+}  // namespace wino
