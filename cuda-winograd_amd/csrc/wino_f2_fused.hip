@@ -10,7 +10,7 @@
 //                x all 16 Winograd points; C is streamed in chunks of BC=8 channels.
 //   wave (wt,wk) = 16 tiles x 32 out-channels x 16 points
 //                = 32 accumulator tiles of v_mfma_f32_16x16x4_f32 (128 acc VGPRs).
-//   per chunk  : LDS-DMA (global_load_lds_dwordx4) stages
+//   per chunk  : LDS-DMA (buffer_load_dwordx4 ... lds) stages
 //                  raw[64 tiles][16 px][8 c]   (the 4x4 input patches, 32 KB, 2 stages)
 //                  U  [16 pts][64 k][8 c]      (pre-packed filter chunk, 32 KB, 3 stages)
 //                two chunks ahead of the MFMAs (all 160 KB of the CU's LDS).
@@ -21,8 +21,9 @@
 //   B operand  : ds_read_b64 of the packed filter chunk.
 //   epilogue   : the 16 accumulators of one (tile, k) sit in the SAME lane/register slot
 //                of 16 different MFMA tiles, so A^T m A is 24 in-lane adds; then
-//                scale*y+bias, ReLU, and 64-byte-segment stores into the padded NHWC
-//                output, plus the zero ring.
+//                scale*y+bias, ReLU; the tile is transposed through LDS and leaves as whole
+//                256-byte pixel rows of the padded NHWC output, plus the zero ring.
+// Small batches (the reference's N = 1) take wino_f2_small_kernel.h instead.
 //
 // LDS bank-conflict avoidance is done by XOR-permuting 16-byte units, applied on the DMA
 // *source* address for the raw patches (the LDS destination of an LDS-DMA is lane-linear)
