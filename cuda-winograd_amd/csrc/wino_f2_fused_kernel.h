@@ -24,7 +24,10 @@ constexpr int N_RSTAGE = 2, N_USTAGE = 3;
 constexpr int LDS_BYTES = N_RSTAGE * RAW_BYTES + N_USTAGE * U_BYTES;  // 163840 = all 160 KiB of the CU
 constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
 constexpr int PF = 2;                        // filter-fragment prefetch distance (points)
-constexpr int DMA0 = 8;                      // first point-step that issues an LDS-DMA piece
+#ifndef WINO_DMA0
+#define WINO_DMA0 4   // tuned with tools/ablate_fused: 0/2/4/6/8 -> 39.4/38.8/38.6/38.7/40.5 cycles per MFMA
+#endif
+constexpr int DMA0 = WINO_DMA0;              // first point-step that issues an LDS-DMA piece
 
 // s_waitcnt lgkmcnt(n) alone (vmcnt/expcnt fields at "no wait"); n folds to a literal once the
 // point loop is unrolled.
@@ -269,7 +272,8 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     // The 8 LDS-DMA pieces this wave contributes per chunk (4 of raw_{it+2} into R[PAR], 4 of
     // U_{it+2} into U[(it+2)%3]) are issued one per step in steps DMA0..DMA0+7 instead of in a
     // burst here: an LDS-DMA instruction holds the wave's issue port for >100 cycles, and
-    // spread out the SIMD's other wave covers that with its MFMAs.
+    // spread out the SIMD's other wave covers that with its MFMAs; starting at step 4 leaves the
+    // last pieces a third of a chunk of flight time before the next chunk's vmcnt(0).
     const bool dma_on = it + 2 < nchunks;
     const char* rst = smem + (PAR ^ 1) * RAW_BYTES;   // raw_{it+1}
     const char* ucur0 = smem + b_base[0] + us_cur * U_BYTES;   // U_it
