@@ -52,10 +52,26 @@ __device__ __forceinline__ void dma16_buf(buffer_rsrc_t rsrc, unsigned voff, uns
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base,
                                            16, voff, soff, 0, 0);
 }
+// 16-byte write-through (sc1) store / L1-bypassing (sc1) load through a buffer descriptor: the
+// pair used for data handed from one workgroup to another inside a launch (per-XCD L2s are not
+// coherent with each other; sc1 stores leave the L2, sc1 loads never hit a stale L1 line).
+typedef unsigned u32x4_vs __attribute__((__vector_size__(16)));
+__device__ __forceinline__ void slab_store16(f32x4 v, buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_vs, v), rsrc, voff, soff, 16);
+}
+__device__ __forceinline__ void buf_store16(f32x4 v, buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_vs, v), rsrc, voff, soff, 0);
+}
+__device__ __forceinline__ f32x4 slab_load16(buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16));
+}
 #else  // host pass: the kernels are only parsed, these builtins do not exist there
 typedef int buffer_rsrc_t;
 __device__ inline buffer_rsrc_t make_rsrc(const void*, unsigned) { return 0; }
 __device__ inline void dma16_buf(buffer_rsrc_t, unsigned, unsigned, void*) {}
+__device__ inline void slab_store16(f32x4, buffer_rsrc_t, unsigned, unsigned) {}
+__device__ inline void buf_store16(f32x4, buffer_rsrc_t, unsigned, unsigned) {}
+__device__ inline f32x4 slab_load16(buffer_rsrc_t, unsigned, unsigned) { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 #endif
 
 __device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

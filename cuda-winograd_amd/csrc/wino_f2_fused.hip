@@ -31,6 +31,8 @@
 #include "wino_f2_small_kernel.h"
 
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 
@@ -164,25 +166,135 @@ int wino_filter_import_f4(const float* u36, float* U, int C, int K, wino_stream_
   return launch_status("filter_import_f4_kernel");
 }
 
-int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
-                         const float* bnScale, float* out, int N, int C, int K, int relu,
-                         wino_stream_t s) {
-  if (!in || !U || !bnBias || !bnScale || !out) { set_error("NULL pointer"); return WINO_E_ARG; }
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------
+// Stream-K workspace: write-through slabs for partial segments (2 per logical workgroup) and one
+// ticket counter per item.  Owned by the library, one per (device, stream) so that launches on
+// different streams never share slabs; allocated on first use (a synchronous hipMalloc: call
+// wino_conv3x3_prepare() first when the launch is going to be captured into a graph).  Counters are
+// zeroed at allocation and returned to zero by every launch's last arrivers.
+// ---------------------------------------------------------------------------------
+struct SkWorkspace {
+  int dev;
+  hipStream_t stream;
+  float* slabs;
+  size_t slab_wgs;     // slabs hold 2 * slab_wgs * SLAB_BYTES
+  unsigned* tickets;
+  size_t n_tickets;
+};
+static std::mutex g_ws_mu;
+static std::vector<SkWorkspace> g_ws;
+
+static int sk_cus(int dev, int* cus) {
+  static std::atomic<int> cache[64];
+  int c = dev >= 0 && dev < 64 ? cache[dev].load() : 0;
+  if (!c) {
+    WINO_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cache[dev].store(c);
+  }
+  *cus = c;
+  return WINO_OK;
+}
+
+static int sk_workspace(int dev, hipStream_t s, int G, size_t items, float** slabs, unsigned** tickets) {
+  items *= 8;   // one ticket counter per (item, wave)
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  SkWorkspace* ws = nullptr;
+  for (auto& e : g_ws)
+    if (e.dev == dev && e.stream == s) ws = &e;
+  if (!ws) {
+    g_ws.push_back(SkWorkspace{dev, s, nullptr, 0, nullptr, 0});
+    ws = &g_ws.back();
+  }
+  if (ws->slab_wgs < (size_t)G) {
+    if (ws->slabs) { WINO_HIP(hipDeviceSynchronize()); WINO_HIP(hipFree(ws->slabs)); ws->slabs = nullptr; ws->slab_wgs = 0; }
+    const size_t wgs = G < 256 ? 256 : (size_t)G;
+    WINO_HIP(hipMalloc((void**)&ws->slabs, 2 * wgs * SLAB_BYTES));
+    ws->slab_wgs = wgs;
+  }
+  if (ws->n_tickets < items) {
+    if (ws->tickets) { WINO_HIP(hipDeviceSynchronize()); WINO_HIP(hipFree(ws->tickets)); ws->tickets = nullptr; ws->n_tickets = 0; }
+    size_t n = 4096;
+    while (n < items) n *= 2;
+    WINO_HIP(hipMalloc((void**)&ws->tickets, n * sizeof(unsigned)));
+    WINO_HIP(hipMemset(ws->tickets, 0, n * sizeof(unsigned)));
+    ws->n_tickets = n;
+  }
+  *slabs = ws->slabs;
+  *tickets = ws->tickets;
+  return WINO_OK;
+}
+
+// Launch geometry of the throughput kernel: G logical workgroups (a multiple of 8, at most one per
+// CU) share T = items * C/8 chunk iterations evenly; small launches keep at least SK_MIN_ITERS
+// iterations per workgroup so that the slab hand-off stays a small part of a workgroup's work.
+constexpr int SK_MIN_ITERS = 8;
+static int sk_grid(int dev, long long T, int* G) {
+  int cus = 0;
+  if (int rc = sk_cus(dev, &cus)) return rc;
+  const char* g_env = getenv("WINO_SK_GRID");        // developer overrides, read per call so that
+  const char* m_env = getenv("WINO_SK_MIN_ITERS");   // tests can sweep the decomposition
+  const int min_iters = m_env && atoi(m_env) > 0 ? atoi(m_env) : SK_MIN_ITERS;
+  long long g = cus & ~7;
+  if (g < 8) g = 8;
+  const long long cap = (T / min_iters) & ~7ll;
+  if (g > cap) g = cap < 8 ? 8 : cap;
+  if (g_env && atoi(g_env) >= 8) g = atoi(g_env) & ~7;
+  *G = (int)g;
+  return WINO_OK;
+}
+
+static int check_conv3x3(int N, int C, int K) {
   if (int rc = check_ck(C, K)) return rc;
   // the kernels address the input with 32-bit byte offsets
   if (N < 1 || (size_t)N * WINO_HW * WINO_HW * (size_t)(C > K ? C : K) * sizeof(float) >= (1ull << 32)) {
     set_error("bad batch N=%d (input/output must stay below 4 GiB)", N);
     return WINO_E_SHAPE;
   }
-  // Two kernels, same arithmetic: the throughput kernel (64 tiles x 64 out-channels per 8-wave
-  // workgroup) and, when that grid would leave most of the 256 CUs idle, the one-wave-per-
-  // workgroup latency kernel (16 tiles x 16 out-channels).  WINO_3X3_ALGO=big|small overrides.
+  // stream-K bookkeeping is 32-bit: chunk iterations in all
+  if ((long long)((N * WINO_TILES + TB - 1) / TB) * (K / KB) * (C / BC) >= (1ll << 31)) {
+    set_error("N=%d C=%d K=%d: too many chunk iterations for one launch", N, C, K);
+    return WINO_E_SHAPE;
+  }
+  return WINO_OK;
+}
+
+// Two kernels, same arithmetic: the throughput kernel (stream-K over 64-tile x 64-out-channel
+// items, 8-wave workgroups) and, when that would still leave most of the 256 CUs idle, the
+// one-wave-per-SIMD latency kernel (16 tiles x 16 out-channels).  WINO_3X3_ALGO=big|small overrides.
+static bool use_small_kernel(int N, int C, int K) {
   const int nTB = (N * WINO_TILES + TB - 1) / TB;
   static const char* algo_env = getenv("WINO_3X3_ALGO");
   bool small = nTB * (K / KB) <= SMALL_MAX_BIG_WGS && (C % 16) == 0;
   if (algo_env && !strcmp(algo_env, "big")) small = false;
   if (algo_env && !strcmp(algo_env, "small")) small = (C % 16) == 0;
-  if (small) {
+  return small;
+}
+
+extern "C" {
+
+int wino_conv3x3_prepare(int N, int C, int K, wino_stream_t s) {
+  if (int rc = check_conv3x3(N, C, K)) return rc;
+  if (use_small_kernel(N, C, K)) return WINO_OK;
+  int dev = 0;
+  WINO_HIP(hipGetDevice(&dev));
+  const int nTB = (N * WINO_TILES + TB - 1) / TB;
+  const size_t items = (size_t)nTB * (K / KB);
+  int G = 0;
+  if (int rc = sk_grid(dev, (long long)items * (C / BC), &G)) return rc;
+  float* slabs;
+  unsigned* tickets;
+  return sk_workspace(dev, (hipStream_t)s, G, items, &slabs, &tickets);
+}
+
+int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
+                         const float* bnScale, float* out, int N, int C, int K, int relu,
+                         wino_stream_t s) {
+  if (!in || !U || !bnBias || !bnScale || !out) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if (int rc = check_conv3x3(N, C, K)) return rc;
+  const int nTB = (N * WINO_TILES + TB - 1) / TB;
+  if (use_small_kernel(N, C, K)) {
     const int nT16 = (N * WINO_TILES + 15) / 16;
     hipLaunchKernelGGL(wino_f2_small_kernel, dim3(nT16, K / 16), dim3(64 * SMALL_WAVES), 0, (hipStream_t)s, in, U,
                        bnBias, bnScale, out, N, C, K, relu);
@@ -197,9 +309,16 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done.fetch_or(1ull << (dev & 63));
   }
-  const int grid = 8 * (K / KB) * ((nTB + 7) / 8);
-  hipLaunchKernelGGL((wino_f2_fused_kernel<0>), dim3(grid), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s,
-                     in, U, bnBias, bnScale, out, N, C, K, relu, nTB);
+  const size_t items = (size_t)nTB * (K / KB);
+  int G = 0;
+  if (int rc = sk_grid(dev, (long long)items * (C / BC), &G)) return rc;
+  float* slabs = nullptr;
+  unsigned* tickets = nullptr;
+  if (int rc = sk_workspace(dev, (hipStream_t)s, G, items, &slabs, &tickets)) return rc;
+  const long long T = (long long)items * (C / BC);
+  hipLaunchKernelGGL((wino_f2_fused_kernel<0>), dim3(G), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s,
+                     in, U, bnBias, bnScale, out, N, C, K, relu, nTB, slabs, tickets,
+                     (unsigned)(T / G), (unsigned)(T % G));
   return launch_status("wino_f2_fused_kernel");
 }
 

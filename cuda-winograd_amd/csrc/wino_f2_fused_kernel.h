@@ -6,6 +6,21 @@
 //   1 skip the raw-patch LDS-DMA      2 skip the filter LDS-DMA      4 skip the MFMAs
 //   8 skip the per-chunk wait+barrier 16 stamp the main loop (in-kernel clock)
 //   32 skip the A-path reads+transform 64 skip the B-fragment reads  512 skip the output stores
+//   1024 skip the stream-K slab hand-off (partial segments are dropped)
+//
+// Work decomposition (stream-K): the launch's work is the linear sequence of "chunk iterations"
+//   (item, chunk),  item = (tile block, k block),  chunk = 8 input channels,
+// T = nTB * K/64 * C/8 of them, all of equal cost.  Logical workgroup l of G takes the contiguous
+// range [l*T/G, (l+1)*T/G): at 256 channels and N = 128, T = 392 * 32 = 12544 = 256 * 49, i.e. every
+// CU gets exactly 49 iterations instead of the 1 or 2 whole items (32 or 64 iterations) of an
+// item-per-workgroup grid.  A range cuts an item into at most two partial SEGMENTS per workgroup
+// (the head of its range, the tail of its range).  A partial segment applies A^T m A to its partial
+// sums (the inverse transform is linear), publishes the 64 KB pre-BN result as a write-through slab
+// and draws a ticket on the item's counter; the workgroup that draws the last ticket adds the other
+// segments' slabs (in segment order, whoever is last: the result is bitwise reproducible), applies
+// BN + ReLU and stores.  Nobody ever waits on another workgroup, so there is no residency
+// assumption and no deadlock; the hand-off follows the write-through recipe (sc1 stores, every
+// storing wave drains vmcnt, barrier, one relaxed agent-scope ticket add, sc1 loads by the reducer).
 #pragma once
 #include "wino_common.h"
 
@@ -24,6 +39,8 @@ constexpr int N_RSTAGE = 2, N_USTAGE = 3;
 constexpr int LDS_BYTES = N_RSTAGE * RAW_BYTES + N_USTAGE * U_BYTES;  // 163840 = all 160 KiB of the CU
 constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
 constexpr int PF = 2;                        // filter-fragment prefetch distance (points)
+constexpr int SLAB_BYTES = TB * 4 * KB * 4;  // 65536: pre-BN output of one item (64 tiles x 2x2 px x 64 k)
+constexpr int FLAG_OFF = LDS_BYTES - 16;     // LDS word that broadcasts the ticket (outside the epilogue image)
 #ifndef WINO_DMA0
 #define WINO_DMA0 4   // tuned with tools/ablate_fused: 0/2/4/6/8 -> 39.4/38.8/38.6/38.7/40.5 cycles per MFMA
 #endif
@@ -76,21 +93,51 @@ __device__ __forceinline__ TileCoord decode_tile(int g) {
   return t;
 }
 
+// Stream-K bookkeeping shared by the kernel and the host (T < 2^31, G <= 65535): logical
+// workgroup l of G owns the iterations [sk_start(l), sk_start(l+1)) of T = q*G + rem, i.e.
+// floor(l*T/G) = l*q + floor(l*rem/G) in 32-bit arithmetic.
+__host__ __device__ inline unsigned sk_start(unsigned l, unsigned q, unsigned rem, unsigned G) {
+  return l * q + l * rem / G;
+}
+
+// In-quad exchange (lanes 4a..4a+3): value of lane ^ 1 / lane ^ 2, by DPP quad_perm.
+__device__ __forceinline__ float quad_xor1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+}
+// 4x4 transpose across the 4 lanes of a quad: lane i holds a[0..3]; afterwards lane i holds
+// { a_of_lane0[i], a_of_lane1[i], a_of_lane2[i], a_of_lane3[i] }.  b0 / b1 = bit 0 / 1 of the lane.
+__device__ __forceinline__ f32x4 quad_transpose(f32x4 a, bool b0, bool b1) {
+  float s, r;
+  s = b0 ? a[0] : a[1]; r = quad_xor1(s); a[0] = b0 ? r : a[0]; a[1] = b0 ? a[1] : r;
+  s = b0 ? a[2] : a[3]; r = quad_xor1(s); a[2] = b0 ? r : a[2]; a[3] = b0 ? a[3] : r;
+  s = b1 ? a[0] : a[2]; r = quad_xor2(s); a[0] = b1 ? r : a[0]; a[2] = b1 ? a[2] : r;
+  s = b1 ? a[1] : a[3]; r = quad_xor2(s); a[1] = b1 ? r : a[1]; a[3] = b1 ? a[3] : r;
+  return a;
+}
+
 template <int ABLATE>
 __global__ void __launch_bounds__(NTHREADS, 2)
 wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
                      const float* __restrict__ bnBias, const float* __restrict__ bnScale,
-                     float* __restrict__ out, int N, int C, int K, int relu, int nTB) {
+                     float* __restrict__ out, int N, int C, int K, int relu, int nTB,
+                     float* __restrict__ slabs, unsigned* __restrict__ tickets,
+                     unsigned sk_q, unsigned sk_rem) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // XCD-aware block -> (tile block, k block): blocks b and b+8 share an XCD (its L2), so the
-  // K/64 k-blocks that read the same input tiles are placed on the same XCD back to back.
+  // XCD-aware block -> logical workgroup: blocks b and b+8 share an XCD (its L2), so consecutive
+  // logical workgroups -- which walk consecutive items, i.e. the K/64 k-blocks that read the same
+  // input tiles -- are placed on the same XCD.  gridDim.x is a multiple of 8.
   const int KBLK = K >> 6;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int kb = slot % KBLK;
-  const int tb = (slot / KBLK) * 8 + xcd;
-  if (tb >= nTB) return;
+  const int nchunks = C / BC;
+  const int G = gridDim.x;
+  const int lg = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  // T = nTB * KBLK * nchunks = sk_q * G + sk_rem chunk iterations in all
+  const unsigned i_begin = sk_start(lg, sk_q, sk_rem, G);
+  const int L = (int)(sk_start(lg + 1, sk_q, sk_rem, G) - i_begin);   // chunk iterations of this workgroup
+  if (L <= 0) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,56 +146,15 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   const int wk = w & 1;   // which 32-channel half of the 64
   const int totalTiles = N * WINO_TILES;
 
-  // ---- DMA source offsets (loop invariant) ------------------------------------
-  // raw stage layout: [tile 0..63][unit' 0..31] of 16 B; unit' = px'*2 + half'.
-  // LDS unit (t, px', half') holds pixel px = px' ^ (t&7), channel half = half' ^ bit3(t).
-  // wave-instruction q = 8*j + w (j = 0..3) covers tiles 2q, 2q+1.
-  // (byte offsets from `in`, 32-bit: the DMA then uses the scalar-base + vector-offset address
-  //  form and advancing to the next chunk is a scalar add instead of a 64-bit VALU add per piece)
-  unsigned raw_off[4];
-  {
-    const int up = lane & 31;
-    const int pxp = up >> 1, halfp = up & 1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int tl = 16 * j + 2 * w + (lane >> 5);
-      const int px = pxp ^ (tl & 7);
-      const int half = halfp ^ ((tl >> 3) & 1);
-      int g = tb * TB + tl;
-      g = g < totalTiles ? g : totalTiles - 1;  // clamp: padded rows read a valid tile
-      const TileCoord tc = decode_tile(g);
-      const int y = 2 * tc.ty + (px >> 2), x = 2 * tc.tx + (px & 3);
-      raw_off[j] = (unsigned)((((size_t)(tc.n * WINO_HW + y) * WINO_HW + x) * C + half * 4) * sizeof(float));
-    }
-  }
   const unsigned u_off = lane * 16;
-  const unsigned u_soff0 = (unsigned)((kb * U_CHUNK_FLOATS + w * 256) * sizeof(float));
   const unsigned u_chunk_stride = (unsigned)(KBLK * U_CHUNK_FLOATS * sizeof(float));
   // buffer descriptors (wave-uniform): everything loop-variant goes into the scalar offset
   const auto rsrc_in = make_rsrc(in, (unsigned)((size_t)N * WINO_HW * WINO_HW * C * sizeof(float)));
   const auto rsrc_u = make_rsrc(Uq, (unsigned)((size_t)16 * C * K * sizeof(float)));
+  const auto rsrc_out = make_rsrc(out, (unsigned)((size_t)N * WINO_HW * WINO_HW * K * sizeof(float)));
+  const auto rsrc_slab = make_rsrc(slabs, (unsigned)((size_t)2 * G * SLAB_BYTES));
 
-  // LDS map: [R0 32K][R1 32K][U0 32K][U1 32K][U2 32K]; R = raw 4x4 patches, U = filter chunk.
-  // Both DMA streams run TWO chunks ahead of the MFMAs:
-  //  * raw_{i+1} is consumed one chunk early: while the MFMAs of chunk i run (operands: V_i in
-  //    registers, U_i in LDS) the wave reads raw_{i+1} from LDS and transforms it into V_{i+1},
-  //    in place over the V registers of points that have already retired, so the matrix pipe
-  //    never waits for the input transform (2 raw stages suffice);
-  //  * U_{i+1} is already visible during chunk i (3 filter stages), so the first filter
-  //    fragments of chunk i+1 are requested BEFORE the chunk barrier and the MFMAs resume right
-  //    after it instead of eating an LDS round trip.
-  auto issue_raw1 = [&](int rstage, int chunk, int j) {  // one 1-KiB piece
-    if (ABLATE & 1) return;
-    dma16_buf(rsrc_in, raw_off[j], (unsigned)(chunk * (BC * sizeof(float))),
-              smem + rstage * RAW_BYTES + (8 * j + w) * 1024);
-  };
-  auto issue_u1 = [&](int ustage, int chunk, int j) {
-    if (ABLATE & 2) return;
-    dma16_buf(rsrc_u, u_off, u_soff0 + chunk * u_chunk_stride + j * 8192,
-              smem + N_RSTAGE * RAW_BYTES + ustage * U_BYTES + (8 * j + w) * 1024);
-  };
-
-  // ---- fragment read addresses (loop invariant) ---------------------------------
+  // ---- fragment read addresses (launch invariant) -------------------------------
   const int t16 = lane & 15, h = lane >> 4;
   // A: tile row tl = wt*16 + t16; 8-byte quarter h holds channels 2h, 2h+1 of the chunk
   const int a_base = (wt * 16 + t16) * 512 + ((h ^ (((t16 >> 3) & 1) << 1)) << 3);
@@ -170,13 +176,6 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     b_base[cb] = N_RSTAGE * RAW_BYTES + kl * 32 + ((h ^ (((kl >> 3) & 1) << 1)) << 3);
   }
   asm volatile("" : "+v"(b_base[1]));
-
-  f32x4 acc[16][2];
-#pragma unroll
-  for (int e = 0; e < 16; e++) {
-    acc[e][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[e][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
 
   // B^T d B pieces (d, tmp, v are [row i][col j] = index 4i + j; Winograd point e = 4i + j).
   // Written per component: with WINO_SCALAR_XFORM the build passes -fno-slp-vectorize so that
@@ -209,12 +208,7 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     if (j == 3) v[e] = sub2(tmp[i * 4 + 1], tmp[i * 4 + 3]);
   };
 
-  const int nchunks = C / BC;
   unsigned long long stamp_c = 0, stamp_r = 0;
-  if (ABLATE & 16) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime)
-    stamp_c = __builtin_amdgcn_s_memtime();
-    stamp_r = __builtin_amdgcn_s_memrealtime();
-  }
   unsigned long long st_wait = 0, st_comp = 0, st_prev = 0;   // ABLATE & 2048: phase stamps
   auto stamp = [&]() -> unsigned long long {
     unsigned long long t;
@@ -223,23 +217,100 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     __builtin_amdgcn_sched_barrier(0);
     return t;
   };
-  P2 v[16];          // V_it at the top of chunk `it`; rewritten in place with V_{it+1}
-  f32x2 bfn[2][2];   // filter fragments of points 0, 1 of the next chunk (requested pre-barrier)
 
-  // ---- prologue: chunks 0 and 1 in flight; V_0 and chunk 0's first fragments un-pipelined --
+  // ---- the DMA stream: walks (item, chunk) linearly, two iterations ahead of the MFMAs ------
+  // raw stage layout: [tile 0..63][unit' 0..31] of 16 B; unit' = px'*2 + half'.
+  // LDS unit (t, px', half') holds pixel px = px' ^ (t&7), channel half = half' ^ bit3(t).
+  // wave-instruction q = 8*j + w (j = 0..3) covers tiles 2q, 2q+1.
+  // (byte offsets from `in`, 32-bit: the DMA then uses the scalar-base + vector-offset address
+  //  form and advancing to the next chunk is a scalar add instead of a 64-bit VALU add per piece)
+  unsigned raw_off[4];        // per-lane source offsets of the DMA stream's tile block
+  unsigned d_soff_raw = 0;    // + chunk * 32 B
+  unsigned d_soff_u = 0;      // filter chunk of (k block, chunk), this wave's 1-KiB column
+  int d_item, d_chunk, d_tb = -1;
+  auto dma_set_item = [&](int item) {   // wave-uniform; the per-lane part only when the tile block changes
+    const int tb = item / KBLK, kb = item - tb * KBLK;
+    d_item = item;
+    if (tb != d_tb) {
+      d_tb = tb;
+      const int up = lane & 31;
+      const int pxp = up >> 1, halfp = up & 1;
 #pragma unroll
-  for (int j = 0; j < 4; j++) issue_raw1(0, 0, j);
+      for (int j = 0; j < 4; j++) {
+        const int tl = 16 * j + 2 * w + (lane >> 5);
+        const int px = pxp ^ (tl & 7);
+        const int half = halfp ^ ((tl >> 3) & 1);
+        int g = tb * TB + tl;
+        g = g < totalTiles ? g : totalTiles - 1;  // clamp: padded rows read a valid tile
+        const TileCoord tc = decode_tile(g);
+        const int y = 2 * tc.ty + (px >> 2), x = 2 * tc.tx + (px & 3);
+        raw_off[j] = (unsigned)((((size_t)(tc.n * WINO_HW + y) * WINO_HW + x) * C + half * 4) * sizeof(float));
+      }
+    }
+    d_soff_raw = (unsigned)(d_chunk * (BC * sizeof(float)));
+    d_soff_u = (unsigned)((kb * U_CHUNK_FLOATS + w * 256) * sizeof(float)) + d_chunk * u_chunk_stride;
+  };
+  auto dma_advance = [&]() {
+    if (++d_chunk == nchunks) {
+      d_chunk = 0;
+      dma_set_item(d_item + 1);
+    } else {
+      d_soff_raw += BC * sizeof(float);
+      d_soff_u += u_chunk_stride;
+    }
+  };
+  // LDS map: [R0 32K][R1 32K][U0 32K][U1 32K][U2 32K]; R = raw 4x4 patches, U = filter chunk.
+  // Both DMA streams run TWO iterations ahead of the MFMAs, across item boundaries:
+  //  * raw_{i+1} is consumed one iteration early: while the MFMAs of iteration i run (operands:
+  //    V_i in registers, U_i in LDS) the wave reads raw_{i+1} from LDS and transforms it into
+  //    V_{i+1}, in place over the V registers of points that have already retired, so the
+  //    matrix pipe never waits for the input transform (2 raw stages suffice);
+  //  * U_{i+1} is already visible during iteration i (3 filter stages), so the first filter
+  //    fragments of iteration i+1 are requested BEFORE the iteration barrier and the MFMAs
+  //    resume right after it instead of eating an LDS round trip.
+  auto issue_raw1 = [&](int rstage, int j) {  // one 1-KiB piece
+    if (ABLATE & 1) return;
+    dma16_buf(rsrc_in, raw_off[j], d_soff_raw, smem + rstage * RAW_BYTES + (8 * j + w) * 1024);
+  };
+  auto issue_u1 = [&](int ustage, int j) {
+    if (ABLATE & 2) return;
+    dma16_buf(rsrc_u, u_off, d_soff_u + j * 8192,
+              smem + N_RSTAGE * RAW_BYTES + ustage * U_BYTES + (8 * j + w) * 1024);
+  };
+
+  // ---- the compute stream's position --------------------------------------------
+  int c_item = (int)(i_begin / (unsigned)nchunks);
+  int c_chunk = (int)(i_begin - (unsigned)c_item * (unsigned)nchunks);
+  int seg_c0 = c_chunk;            // first chunk of the current segment
+  int pend_item = -1;              // a head segment whose ticket is still to be drawn
+
+  f32x4 acc[16][2];
 #pragma unroll
-  for (int j = 0; j < 4; j++) issue_u1(0, 0, j);
+  for (int e = 0; e < 16; e++) {
+    acc[e][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[e][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  P2 v[16];          // V_it at the top of iteration `it`; rewritten in place with V_{it+1}
+  f32x2 bfn[2][2];   // filter fragments of points 0, 1 of the next iteration (requested pre-barrier)
+
+  // ---- prologue: iterations 0 and 1 in flight; V_0 and the first fragments un-pipelined -----
+  d_chunk = c_chunk;
+  dma_set_item(c_item);
+#pragma unroll
+  for (int j = 0; j < 4; j++) issue_raw1(0, j);
+#pragma unroll
+  for (int j = 0; j < 4; j++) issue_u1(0, j);
+  dma_advance();
   if (!(ABLATE & 8)) {
     wait_vmem_all();
     __syncthreads();
   }
-  if (nchunks > 1) {
+  if (L > 1) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) issue_raw1(1, 1, j);
+    for (int j = 0; j < 4; j++) issue_raw1(1, j);
 #pragma unroll
-    for (int j = 0; j < 4; j++) issue_u1(1, 1, j);
+    for (int j = 0; j < 4; j++) issue_u1(1, j);
+    dma_advance();
   }
   {
     P2 d[16], tmp[16];
@@ -255,9 +326,13 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       bfn[e][1] = *(const f32x2*)(smem + b_base[1] + e * 2048);
     }
   }
+  if (ABLATE & 16) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime)
+    stamp_c -= __builtin_amdgcn_s_memtime();
+    stamp_r -= __builtin_amdgcn_s_memrealtime();
+  }
 
-  // One pipeline step = chunk `it`.  PAR = it & 1 is a compile-time constant (the loop is
-  // unrolled by two) so that the raw-stage offsets fold into the ds_read immediates; the
+  // One pipeline step = iteration `it`.  PAR = it & 1 is a compile-time constant (two
+  // instantiations) so that the raw-stage offsets fold into the ds_read immediates; the
   // filter stage (it % 3) is a run-time offset added to the two fragment base registers.
   // The schedule inside is pinned with sched_barrier(0): left alone, hipcc sinks every
   // ds_read to just before its first use and the wave eats one LDS latency per point.
@@ -269,12 +344,12 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       __syncthreads();   // everyone's have; everyone is done with the stages refilled below
     }
     if (ABLATE & 2048) { const unsigned long long t = stamp(); st_wait += t - st_prev; st_prev = t; }
-    // The 8 LDS-DMA pieces this wave contributes per chunk (4 of raw_{it+2} into R[PAR], 4 of
+    // The 8 LDS-DMA pieces this wave contributes per iteration (4 of raw_{it+2} into R[PAR], 4 of
     // U_{it+2} into U[(it+2)%3]) are issued one per step in steps DMA0..DMA0+7 instead of in a
     // burst here: an LDS-DMA instruction holds the wave's issue port for >100 cycles, and
     // spread out the SIMD's other wave covers that with its MFMAs; starting at step 4 leaves the
-    // last pieces a third of a chunk of flight time before the next chunk's vmcnt(0).
-    const bool dma_on = it + 2 < nchunks;
+    // last pieces a third of an iteration of flight time before the next vmcnt(0).
+    const bool dma_on = it + 2 < L;
     const char* rst = smem + (PAR ^ 1) * RAW_BYTES;   // raw_{it+1}
     const char* ucur0 = smem + b_base[0] + us_cur * U_BYTES;   // U_it
     const char* ucur1 = smem + b_base[1] + us_cur * U_BYTES;
@@ -297,18 +372,18 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       } else if (e + PF < 16) {  // filter fragments of point e+PF
         bf[e + PF][0] = *(const f32x2*)(ucur0 + (e + PF) * 2048);
         bf[e + PF][1] = *(const f32x2*)(ucur1 + (e + PF) * 2048);
-      } else {                   // ... and of points 0, 1 of the next chunk
+      } else {                   // ... and of points 0, 1 of the next iteration
         bfn[e + PF - 16][0] = *(const f32x2*)(unxt0 + (e + PF - 16) * 2048);
         bfn[e + PF - 16][1] = *(const f32x2*)(unxt1 + (e + PF - 16) * 2048);
       }
       if (e >= DMA0 && e < DMA0 + 4) {
-        if (dma_on) issue_raw1(PAR, it + 2, e - DMA0);
+        if (dma_on) issue_raw1(PAR, e - DMA0);
       } else if (e >= DMA0 + 4 && e < DMA0 + 8) {
-        if (dma_on) issue_u1(us_dma, it + 2, e - DMA0 - 4);
+        if (dma_on) issue_u1(us_dma, e - DMA0 - 4);
       }
-      // next chunk's A operand rides along: steps 0-7 read the patch (two pixels of patch
+      // next iteration's A operand rides along: steps 0-7 read the patch (two pixels of patch
       // column e>>1 per step), steps 2,4,6,8 form B^T d column by column, steps 9-15 form
-      // (B^T d) B in place over the points that have retired.  (After the last chunk this
+      // (B^T d) B in place over the points that have retired.  (After the last iteration this
       // works on stale LDS; the result is never used -- cheaper than a branch per step.)
       if (e < 8 && !(ABLATE & 32)) {
         const int j = e >> 1, i0 = (e & 1) * 2;
@@ -345,48 +420,35 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     }
   };
 
-  {
-    int us = 0;  // filter stage of chunk `it` (= it % 3)
-    auto next = [](int s) { return s == 2 ? 0 : s + 1; };
-    for (int it = 0; it < nchunks; it += 2) {
-      body(std::integral_constant<int, 0>{}, it, us, next(us), next(next(us)));
-      us = next(us);
-      if (it + 1 < nchunks) {
-        body(std::integral_constant<int, 1>{}, it + 1, us, next(us), next(next(us)));
-        us = next(us);
-      }
+  // ---- per-wave epilogue pieces (no LDS, no barrier: the DMA pipeline keeps running) ----------
+  // Slab image of one partial segment: [wave 0..7][q = 2r+cb][lane] of 16 B (the 2x2 output
+  // pixels of tile row 4h+r, out-channel cb*16+t16, pre-BN).  Waves hand their 8 KiB parts over
+  // independently: wave w of every segment of an item draws on tickets[8*item + w].
+  const unsigned slab_voff = (unsigned)((w * 8 * 64 + lane) * 16);
+  // all segments' parts of `item`, summed in segment order (bitwise reproducible whoever
+  // reduces); the item's segments belong to the non-empty workgroups among gA..gB
+  auto gather = [&](f32x4 (&y)[4][2], int gA, int gB) {
+    bool first = true;
+#pragma unroll 1
+    for (int g = gA; g <= gB; g++) {
+      if (sk_start(g + 1, sk_q, sk_rem, G) == sk_start(g, sk_q, sk_rem, G)) continue;   // owns nothing
+      const unsigned slot = 2u * (unsigned)g + (first ? 1u : 0u);
+      f32x4 t[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) t[q] = slab_load16(rsrc_slab, slab_voff + q * 1024, slot * SLAB_BYTES);
+#pragma unroll
+      for (int q = 0; q < 8; q++) y[q >> 1][q & 1] = first ? t[q] : y[q >> 1][q & 1] + t[q];
+      first = false;
     }
-  }
-#undef A_OFF
-  if (ABLATE & 2048) {
-    st_comp += stamp() - st_prev;
-    if (lane == 0) {
-      unsigned long long* dbg = (unsigned long long*)(out + (size_t)N * WINO_HW * WINO_HW * K) +
-                                ((size_t)(tb * KBLK + kb) * 8 + w) * 2;
-      dbg[0] = st_wait;
-      dbg[1] = st_comp;
-    }
-  }
-  if (ABLATE & 16) {
-    stamp_c = __builtin_amdgcn_s_memtime() - stamp_c;
-    stamp_r = __builtin_amdgcn_s_memrealtime() - stamp_r;
-    if (tid == 0) {  // stamps go past the N images of `out` (the tool allocates that room)
-      unsigned long long* dbg =
-          (unsigned long long*)(out + (size_t)N * WINO_HW * WINO_HW * K) + (size_t)(tb * KBLK + kb) * 2;
-      dbg[0] = stamp_c;
-      dbg[1] = stamp_r;
-    }
-  }
-
-  // ---- epilogue: A^T m A, BN, ReLU (C/D layout: col = lane&15, row = 4*(lane>>4)+r), then the
-  // output tile goes through LDS so that it leaves as whole 256-byte pixel rows (dwordx4 per
-  // lane) instead of 64-byte fragments.
-  // LDS image: Y[tile 0..63][px 0..3][k 0..63] floats, tile stride EP_TS (260: the +4 puts the
-  // two tile rows a 32-lane ds_write_b32 group touches on disjoint banks).
-  constexpr int EP_TS = 4 * KB + 4;
-  __syncthreads();  // every wave is done with the pipeline stages; no LDS-DMA is in flight
-  float* ylds = (float*)smem;
-  {
+  };
+  // BN + ReLU, 4x4 quad transposes (lane (a,i) of a quad ends up with pixel i, out-channels
+  // 4a..4a+3), 16-byte stores into the padded NHWC output, zero ring next to edge tiles
+  // (the next 3x3 layer's padding, Kernel128_winograd.cu:163,243).
+  auto finalize = [&](int item, f32x4 (&y)[4][2]) {
+    if (ABLATE & 512) return;  // price the store tail
+    const int tb = item / KBLK, kb = item - tb * KBLK;
+    const int qi = t16 & 3, qa = t16 >> 2;
+    const bool b0 = qi & 1, b1 = qi & 2;
     float sc[2], bi[2];
 #pragma unroll
     for (int cb = 0; cb < 2; cb++) {
@@ -394,6 +456,72 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       sc[cb] = bnScale[kc];
       bi[cb] = bnBias[kc];
     }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int g = tb * TB + wt * 16 + 4 * h + r;
+      const bool live = g < totalTiles;
+      const TileCoord tc = decode_tile(live ? g : 0);
+      const int py = 1 + 2 * tc.ty + (qi >> 1), px = 1 + 2 * tc.tx + (qi & 1);
+      const unsigned kbyte = (unsigned)((kb * KB + wk * 32 + 4 * qa) * sizeof(float));
+      const unsigned img = (unsigned)(tc.n * WINO_HW * WINO_HW);
+      const unsigned o_main = (unsigned)((img + py * WINO_HW + px) * K * sizeof(float)) + kbyte;
+      // ring pixels adjacent to this lane's pixel
+      const bool rrow = live && (py == 1 || py == WINO_PQ), rcol = live && (px == 1 || px == WINO_PQ);
+      const int ry = py == 1 ? 0 : WINO_HW - 1, rx = px == 1 ? 0 : WINO_HW - 1;
+      const unsigned o_row = (unsigned)((img + ry * WINO_HW + px) * K * sizeof(float)) + kbyte;
+      const unsigned o_col = (unsigned)((img + py * WINO_HW + rx) * K * sizeof(float)) + kbyte;
+      const unsigned o_cor = (unsigned)((img + ry * WINO_HW + rx) * K * sizeof(float)) + kbyte;
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++) {
+        f32x4 val;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          float v1 = sc[cb] * y[r][cb][p] + bi[cb];
+          if (relu) v1 = fmaxf(v1, 0.f);
+          val[p] = v1;
+        }
+        val = quad_transpose(val, b0, b1);
+        const unsigned so = (unsigned)(cb * 16 * sizeof(float));
+        if (live) buf_store16(val, rsrc_out, o_main, so);
+        if (rrow) buf_store16(zero4, rsrc_out, o_row, so);
+        if (rcol) buf_store16(zero4, rsrc_out, o_col, so);
+        if (rrow && rcol) buf_store16(zero4, rsrc_out, o_cor, so);
+      }
+    }
+  };
+  auto draw_ticket = [&](int item) -> unsigned {   // one returning agent-scope add per wave
+    unsigned old = 0;
+    if (lane == 0)
+      old = __hip_atomic_fetch_add(tickets + (size_t)item * 8 + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return old;   // meaningful in lane 0; readfirstlane at the use
+  };
+  // which logical workgroups share `item` (one this workgroup works on): walk outwards from lg.
+  // With more workgroups than iterations some own nothing; they are not segments.
+  auto item_segments = [&](int item, int& gA, int& gB, int& nseg) {
+    const unsigned x0 = (unsigned)item * (unsigned)nchunks, x1 = x0 + nchunks - 1;
+    int a = lg, b = lg;
+    while (sk_start(a, sk_q, sk_rem, G) > x0) a--;
+    while (b + 1 < G && sk_start(b + 1, sk_q, sk_rem, G) <= x1) b++;
+    int n = 0;
+    for (int g = a; g <= b; g++)
+      n += sk_start(g + 1, sk_q, sk_rem, G) != sk_start(g, sk_q, sk_rem, G);
+    gA = a;
+    gB = b;
+    nseg = n;
+  };
+
+  // A segment ends with the item's last chunk or with the range.  Whole segments are finalized
+  // from registers.  A partial segment publishes its slab part; if more work follows (it is the
+  // head of the range) its ticket is drawn one segment later, when the stores have long drained
+  // and registers are free again; the range's last segment draws at once.  Whoever draws an
+  // item's last ticket gathers all parts and finalizes.
+  auto epilogue = [&](bool last_of_range) {
+    unsigned pend_old = 0;
+    if (pend_item >= 0) pend_old = draw_ticket(pend_item);   // in flight while A^T m A runs
+    // A^T m A (C/D layout: col = lane&15, row = 4*(lane>>4)+r):
+    // y[r][cb] = the 2x2 output pixels (p = 2a+b) of tile row 4h+r, out-channel cb*16+t16.
+    f32x4 y[4][2];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -406,52 +534,107 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
           t0[j] = m0 + m1 + m2;
           t1[j] = m1 - m2 - m3;
         }
-        float y[4];
-        y[0] = t0[0] + t0[1] + t0[2];
-        y[1] = t0[1] - t0[2] - t0[3];
-        y[2] = t1[0] + t1[1] + t1[2];
-        y[3] = t1[1] - t1[2] - t1[3];
-        float* yl = ylds + (wt * 16 + 4 * h + r) * EP_TS + wk * 32 + cb * 16 + t16;
+        y[r][cb][0] = t0[0] + t0[1] + t0[2];
+        y[r][cb][1] = t0[1] - t0[2] - t0[3];
+        y[r][cb][2] = t1[0] + t1[1] + t1[2];
+        y[r][cb][3] = t1[1] - t1[2] - t1[3];
+      }
+    }
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-          float v1 = sc[cb] * y[p] + bi[cb];
-          if (relu) v1 = fmaxf(v1, 0.f);
-          yl[p * KB] = v1;
-        }
+    for (int e = 0; e < 16; e++) {
+      acc[e][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[e][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool whole = seg_c0 == 0 && c_chunk == nchunks - 1;
+    // up to two items to look at: [0] this segment's, [1] the deferred head segment's
+    int job0 = -1, job1 = -1;
+    unsigned old0 = 0;
+    if (whole) {
+      job0 = c_item;
+    } else if (!(ABLATE & 1024)) {
+      const unsigned my_slot = 2u * lg + (seg_c0 == 0 ? 1u : 0u);
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        slab_store16(y[q >> 1][q & 1], rsrc_slab, slab_voff + q * 1024, my_slot * SLAB_BYTES);
+      if (!last_of_range) {
+        pend_item = c_item;        // ticket deferred to the next segment's epilogue
+      } else {
+        wait_vmem_all();           // this wave's write-through stores have left ...
+        old0 = draw_ticket(c_item);   // ... before its ticket
+        job0 = c_item;
+      }
+    }
+    if (pend_item >= 0 && pend_item != c_item) {
+      job1 = pend_item;
+      pend_item = -1;
+    }
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+      const int item = j == 0 ? job0 : job1;
+      if (item < 0) continue;
+      if (!(j == 0 && whole)) {
+        int gA, gB, nseg;
+        item_segments(item, gA, gB, nseg);
+        const unsigned old = __builtin_amdgcn_readfirstlane(j == 0 ? old0 : pend_old);
+        if (old != (unsigned)(nseg - 1)) continue;   // another workgroup's wave w will finish the item
+        if (lane == 0)   // self-cleaning counter: the next launch finds 0 again
+          __hip_atomic_store(tickets + (size_t)item * 8 + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gather(y, gA, gB);
+      }
+      finalize(item, y);
+    }
+  };
+
+  // ================================ main loop =====================================
+  {
+    int us = 0;  // filter stage of iteration `it` (= it % 3)
+    auto next = [](int s) { return s == 2 ? 0 : s + 1; };
+    // after the MFMAs of iteration `it`: move the DMA stream on; close the segment if it ends here
+    auto post = [&](int it) {
+      if (it + 2 < L) dma_advance();
+      const bool last_of_range = it == L - 1;
+      if (c_chunk == nchunks - 1 || last_of_range) {
+        if (ABLATE & 2048) st_comp += stamp() - st_prev;
+        epilogue(last_of_range);
+        if (ABLATE & 2048) st_prev = stamp();
+        c_item++;
+        c_chunk = 0;
+        seg_c0 = 0;
+      } else {
+        c_chunk++;
+      }
+    };
+#pragma unroll 1
+    for (int it = 0; it < L; it += 2) {
+      body(std::integral_constant<int, 0>{}, it, us, next(us), next(next(us)));
+      us = next(us);
+      post(it);
+      if (it + 1 < L) {
+        body(std::integral_constant<int, 1>{}, it + 1, us, next(us), next(next(us)));
+        us = next(us);
+        post(it + 1);
       }
     }
   }
-  __syncthreads();
-  if (ABLATE & 512) return;  // price the store tail
-  // wave w stores tiles 8w .. 8w+7 of the block; one instruction = one tile = 4 pixel rows of
-  // 256 B: lane -> pixel (lane>>4) = (a,b), 16-byte chunk (lane&15) of the 64 out-channels
-  {
-    const int pxl = lane >> 4, chunk = lane & 15;
-    float* ocol = out + kb * KB + chunk * 4;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int tl = 8 * w + i;
-      const int g = tb * TB + tl;
-      if (g >= totalTiles) break;  // wave-uniform
-      const TileCoord tc = decode_tile(g);
-      const int oy = 1 + 2 * tc.ty, ox = 1 + 2 * tc.tx;
-      float* img = ocol + (size_t)tc.n * WINO_HW * WINO_HW * K;
-      const f32x4 val = *(const f32x4*)(ylds + tl * EP_TS + pxl * KB + chunk * 4);
-      *(f32x4*)(img + (size_t)((oy + (pxl >> 1)) * WINO_HW + ox + (pxl & 1)) * K) = val;
-      // zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:163,243): edge tiles
-      // also clear the ring pixels next to them; lane group 2 takes the corner.  All
-      // conditions on tc are wave-uniform.
-      if (tc.ty == 0 || tc.ty == 6) {
-        const int ry = tc.ty == 0 ? 0 : 15;
-        const bool corner = tc.tx == 0 || tc.tx == 6;
-        const int rx = pxl < 2 ? ox + pxl : (tc.tx == 0 ? 0 : 15);
-        if (pxl < 2 || (pxl == 2 && corner)) *(f32x4*)(img + (size_t)(ry * WINO_HW + rx) * K) = zero4;
-      }
-      if (tc.tx == 0 || tc.tx == 6) {
-        const int rx = tc.tx == 0 ? 0 : 15;
-        if (pxl < 2) *(f32x4*)(img + (size_t)((oy + pxl) * WINO_HW + rx) * K) = zero4;
-      }
+#undef A_OFF
+
+  // diagnostic builds: stamps go past the N images of `out` (the tool allocates that room)
+  if (ABLATE & 2048) {
+    if (lane == 0) {
+      unsigned long long* dbg = (unsigned long long*)(out + (size_t)N * WINO_HW * WINO_HW * K) +
+                                ((size_t)lg * 8 + w) * 2;
+      dbg[0] = st_wait;
+      dbg[1] = st_comp;
+    }
+  }
+  if (ABLATE & 16) {
+    stamp_c += __builtin_amdgcn_s_memtime();
+    stamp_r += __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      unsigned long long* dbg =
+          (unsigned long long*)(out + (size_t)N * WINO_HW * WINO_HW * K) + (size_t)lg * 2;
+      dbg[0] = stamp_c;
+      dbg[1] = stamp_r;
     }
   }
 }

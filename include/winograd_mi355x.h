@@ -100,10 +100,18 @@ int wino_filter_import_f4(const float* u36, float* U, int C, int K, wino_stream_
  *                       (= the next 3x3 layer's padded input, Kernel128_winograd.cu:163)
  * out = relu(bnScale[k] * conv + bnBias[k]);  argument order (in, bias, scale, out)
  * follows kernel_*_winograd_AtIA (Kernel128_winograd.cu:123).
- * Constraints: C % 8 == 0, K % 64 == 0, N >= 1.  One launch, no workspace. */
+ * Constraints: C % 8 == 0, K % 64 == 0, N >= 1.  One launch.  The throughput kernel splits the
+ * work evenly over the CUs (stream-K) and hands partial sums between workgroups through a small
+ * scratch buffer the LIBRARY owns, one per (device, stream), allocated at the first call that needs
+ * it (a synchronous hipMalloc).  Launches on one stream serialise, so they share it safely; two
+ * host threads must not launch on the SAME stream concurrently. */
 int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
                          const float* bnScale, float* out, int N, int C, int K, int relu,
                          wino_stream_t s);
+/* Allocates that scratch for (current device, `s`) and this shape ahead of time -- e.g. before
+ * capturing wino_conv3x3_bn_relu / wino_residual_block into a HIP graph, where an allocation inside
+ * the capture is not allowed.  Optional otherwise. */
+int wino_conv3x3_prepare(int N, int C, int K, wino_stream_t s);
 
 /* Independent comparator: direct (non-Winograd) 3x3 conv + BN + ReLU on the GPU,
  * w_kcrs [K][C][3][3]; same in/out layout as above.  Slow by design. */

@@ -12,19 +12,31 @@ using namespace wino::fused;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+static float* g_slabs;
+static unsigned* g_tickets;
+static int g_grid = 256;   // logical workgroups (argv[2]); 0 = one whole item per workgroup
+
+static int grid_for(int N, int K) {
+  const int nTB = (N * 49 + TB - 1) / TB;
+  if (g_grid) return g_grid;
+  return (nTB * (K / KB) + 7) & ~7;   // item-per-workgroup when the item count is a multiple of 8
+}
+
 template <int AB>
 float run(const float* in, const float* U, const float* b, const float* s, float* out, int N, int C, int K, int reps) {
   CK(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<AB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   const int nTB = (N * 49 + TB - 1) / TB;
-  const int grid = 8 * (K / KB) * ((nTB + 7) / 8);
+  const int grid = grid_for(N, K);
+  CK(hipMemset(g_tickets, 0, 65536 * 4));   // ablated variants may leave tickets behind
+  const unsigned T = (unsigned)nTB * (K / KB) * (C / 8);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; i++)
-    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB);
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB, g_slabs, g_tickets, T / grid, T % grid);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < reps; i++)
-    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB);
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB, g_slabs, g_tickets, T / grid, T % grid);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -34,6 +46,9 @@ float run(const float* in, const float* U, const float* b, const float* s, float
 
 int main(int argc, char** argv) {
   const int C = argc > 1 ? atoi(argv[1]) : 256, K = C;
+  if (argc > 2) g_grid = atoi(argv[2]) & ~7;
+  CK(hipMalloc(&g_slabs, (size_t)2 * 4096 * SLAB_BYTES));
+  CK(hipMalloc(&g_tickets, 65536 * 4));
   std::vector<int> Ns = {1, 83, 128};
   const size_t maxN = 256;
   float *in, *U, *b, *s, *out;
@@ -44,38 +59,42 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(U, h.data(), (size_t)16 * C * K * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b, h.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + K, K * 4, hipMemcpyHostToDevice));
-  printf("C=K=%d   us per launch; WGs = 4*ceil(N*49/64) (K/64 k-blocks)\n", C);
-  printf("%6s %6s | %8s %8s %8s %8s %8s\n", "N", "WGs", "full", "noRawDMA", "noUDMA", "noDMA", "noMFMA");
+  printf("C=K=%d   us per launch; items = K/64 * ceil(N*49/64); grid = %d logical workgroups (0: one item each)\n", C, g_grid);
+  printf("%6s %6s %6s | %8s %8s %8s %8s %8s %8s %8s %8s\n", "N", "items", "grid", "full", "noRawDMA", "noUDMA", "noDMA", "noMFMA",
+         "noBarr", "noStore", "noSlab");
   for (int N : Ns) {
-    const int wgs = (K / 64) * ((N * 49 + 63) / 64);
-    printf("%6d %6d | %8.1f %8.1f %8.1f %8.1f %8.1f\n", N, wgs,
+    const int items = (K / 64) * ((N * 49 + 63) / 64);
+    printf("%6d %6d %6d | %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f\n", N, items, grid_for(N, K),
            run<0>(in, U, b, s, out, N, C, K, 20), run<1>(in, U, b, s, out, N, C, K, 20),
            run<2>(in, U, b, s, out, N, C, K, 20), run<3>(in, U, b, s, out, N, C, K, 20),
-           run<4>(in, U, b, s, out, N, C, K, 20));
+           run<4>(in, U, b, s, out, N, C, K, 20), run<8>(in, U, b, s, out, N, C, K, 20),
+           run<512>(in, U, b, s, out, N, C, K, 20), run<1024>(in, U, b, s, out, N, C, K, 20));
   }
   {  // in-kernel clock of the main loop (diagnostic build, ABLATE bit 16)
     const int N = 128;
-    const int nTB = (N * 49 + TB - 1) / TB, wgs = nTB * (K / KB);
+    const int nTB = (N * 49 + TB - 1) / TB, wgs = grid_for(N, K);
+    const double iters = (double)nTB * (K / KB) * (C / 8) / wgs;   // chunk iterations per workgroup
     run<16>(in, U, b, s, out, N, C, K, 3);
     std::vector<unsigned long long> st((size_t)wgs * 2);
     CK(hipMemcpy(st.data(), out + (size_t)N * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
     double cyc = 0, rt = 0, cmin = 1e30, cmax = 0;
     for (int i = 0; i < wgs; i++) { cyc += st[2 * i]; rt += st[2 * i + 1]; cmin = std::min(cmin, (double)st[2 * i]); cmax = std::max(cmax, (double)st[2 * i]); }
     printf("main loop, N=128: in-kernel clock %.3f GHz; cycles per WG pass mean %.0f min %.0f max %.0f (= %.1f cycles per MFMA per SIMD)\n",
-           cyc / rt * 0.1, cyc / wgs, cmin, cmax, cyc / wgs / (C / 8) / 128.0);
+           cyc / rt * 0.1, cyc / wgs, cmin, cmax, cyc / wgs / iters / 128.0);
   }
   {  // per-wave phase stamps (ABLATE bit 2048): barrier+DMA wait vs compute, in shader cycles
     const int N = 128;
-    const int nTB = (N * 49 + TB - 1) / TB, wgs = nTB * (K / KB);
+    const int nTB = (N * 49 + TB - 1) / TB, wgs = grid_for(N, K);
+    const double iters = (double)nTB * (K / KB) * (C / 8) / wgs;
     run<2048>(in, U, b, s, out, N, C, K, 2);
     std::vector<unsigned long long> st((size_t)wgs * 16);
     CK(hipMemcpy(st.data(), out + (size_t)N * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
     double wsum[8] = {0}, csum[8] = {0};
     for (int i = 0; i < wgs; i++) for (int w = 0; w < 8; w++) { wsum[w] += st[(i * 8 + w) * 2]; csum[w] += st[(i * 8 + w) * 2 + 1]; }
-    printf("per chunk (C/8 = %d chunks), mean over %d workgroups; stamps add overhead, read the SHARES:\n", C / 8, wgs);
+    printf("per chunk iteration (%.2f per workgroup), mean over %d workgroups; stamps add overhead, read the SHARES:\n", iters, wgs);
     for (int w = 0; w < 8; w++)
       printf("  wave %d: wait(vmcnt+barrier) %7.0f cycles  compute %7.0f cycles  wait share %.1f%%\n", w,
-             wsum[w] / wgs / (C / 8), csum[w] / wgs / (C / 8), 100.0 * wsum[w] / (wsum[w] + csum[w]));
+             wsum[w] / wgs / iters, csum[w] / wgs / iters, 100.0 * wsum[w] / (wsum[w] + csum[w]));
   }
   return 0;
 }
