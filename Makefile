@@ -45,6 +45,9 @@ tools/ablate_1x1: tools/ablate_1x1.hip $(wildcard $(CSRC)/*.h)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) $< -o $@
 tools/ablate_fused: tools/ablate_fused.hip $(wildcard $(CSRC)/*.h)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) $< -o $@
+# experiment variants of the ablation tool: make tools/xab_NAME XFLAGS="-DWINO_DMA_MODE=1"
+tools/xab_%: tools/ablate_fused.hip $(wildcard $(CSRC)/*.h)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) $(XFLAGS) tools/ablate_fused.hip -o $@
 tools/mfma_peak: tools/mfma_peak.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 

@@ -316,9 +316,9 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
   unsigned* tickets = nullptr;
   if (int rc = sk_workspace(dev, (hipStream_t)s, G, items, &slabs, &tickets)) return rc;
   const long long T = (long long)items * (C / BC);
-  hipLaunchKernelGGL((wino_f2_fused_kernel<0>), dim3(G), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s,
-                     in, U, bnBias, bnScale, out, N, C, K, relu, nTB, slabs, tickets,
-                     (unsigned)(T / G), (unsigned)(T % G));
+  const FusedParams prm = {in, U, N, C, K, relu, nTB, (unsigned)(T / G), (unsigned)(T % G),
+                           bnBias, bnScale, out, slabs, tickets};
+  hipLaunchKernelGGL((wino_f2_fused_kernel<0>), dim3(G), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s, prm);
   return launch_status("wino_f2_fused_kernel");
 }
 

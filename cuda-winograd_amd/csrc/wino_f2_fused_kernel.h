@@ -45,6 +45,18 @@ constexpr int FLAG_OFF = LDS_BYTES - 16;     // LDS word that broadcasts the tic
 #define WINO_DMA0 4   // tuned with tools/ablate_fused: 0/2/4/6/8 -> 39.4/38.8/38.6/38.7/40.5 cycles per MFMA
 #endif
 constexpr int DMA0 = WINO_DMA0;              // first point-step that issues an LDS-DMA piece
+#ifndef WINO_PRIO
+#define WINO_PRIO 0
+#endif
+#ifndef WINO_PIN
+#define WINO_PIN 0
+#endif
+#ifndef WINO_MFMA_ASM
+#define WINO_MFMA_ASM 1
+#endif
+#ifndef WINO_DMA_MODE
+#define WINO_DMA_MODE 0   // 0: one piece per step, all waves in the same steps; 1: two pieces per step, SIMD mates in alternate steps
+#endif
 
 // s_waitcnt lgkmcnt(n) alone (vmcnt/expcnt fields at "no wait"); n folds to a literal once the
 // point loop is unrolled.
@@ -118,14 +130,30 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 a, bool b0, bool b1) {
   return a;
 }
 
+// The kernel's only argument.  The fields below the line are used by the epilogue alone: it
+// re-reads them from the kernarg segment each time instead of keeping ~20 scalar registers
+// (pointers + two buffer descriptors) alive across the main loop, which is out of SGPRs.
+struct FusedParams {
+  const float* in;
+  const float* Uq;
+  int N, C, K, relu, nTB;
+  unsigned sk_q, sk_rem;       // T = nTB * K/64 * C/8 = sk_q * gridDim.x + sk_rem
+  // ---- epilogue only ----
+  const float* bnBias;
+  const float* bnScale;
+  float* out;
+  float* slabs;
+  unsigned* tickets;
+};
+
 template <int ABLATE>
 __global__ void __launch_bounds__(NTHREADS, 2)
-wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
-                     const float* __restrict__ bnBias, const float* __restrict__ bnScale,
-                     float* __restrict__ out, int N, int C, int K, int relu, int nTB,
-                     float* __restrict__ slabs, unsigned* __restrict__ tickets,
-                     unsigned sk_q, unsigned sk_rem) {
+wino_f2_fused_kernel(const FusedParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const float* __restrict__ in = prm.in;
+  const float* __restrict__ Uq = prm.Uq;
+  const int N = prm.N, C = prm.C, K = prm.K, relu = prm.relu, nTB = prm.nTB;
+  const unsigned sk_q = prm.sk_q, sk_rem = prm.sk_rem;
 
   // XCD-aware block -> logical workgroup: blocks b and b+8 share an XCD (its L2), so consecutive
   // logical workgroups -- which walk consecutive items, i.e. the K/64 k-blocks that read the same
@@ -151,8 +179,6 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   // buffer descriptors (wave-uniform): everything loop-variant goes into the scalar offset
   const auto rsrc_in = make_rsrc(in, (unsigned)((size_t)N * WINO_HW * WINO_HW * C * sizeof(float)));
   const auto rsrc_u = make_rsrc(Uq, (unsigned)((size_t)16 * C * K * sizeof(float)));
-  const auto rsrc_out = make_rsrc(out, (unsigned)((size_t)N * WINO_HW * WINO_HW * K * sizeof(float)));
-  const auto rsrc_slab = make_rsrc(slabs, (unsigned)((size_t)2 * G * SLAB_BYTES));
 
   // ---- fragment read addresses (launch invariant) -------------------------------
   const int t16 = lane & 15, h = lane >> 4;
@@ -209,7 +235,8 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   };
 
   unsigned long long stamp_c = 0, stamp_r = 0;
-  unsigned long long st_wait = 0, st_comp = 0, st_prev = 0;   // ABLATE & 2048: phase stamps
+  unsigned long long st_wait = 0, st_comp = 0, st_epi = 0, st_prev = 0;   // ABLATE & 2048: phase stamps
+  unsigned long long st_ph[4] = {0, 0, 0, 0};   // epilogue phases: barrier, A^T m A, slab+ticket, gather+finalize
   auto stamp = [&]() -> unsigned long long {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -326,31 +353,35 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       bfn[e][1] = *(const f32x2*)(smem + b_base[1] + e * 2048);
     }
   }
+#pragma unroll
+  for (int p = 0; p < 8; p++) a_lo[p] ^= RAW_BYTES;   // iteration 0 reads raw_1 from R1
   if (ABLATE & 16) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime)
     stamp_c -= __builtin_amdgcn_s_memtime();
     stamp_r -= __builtin_amdgcn_s_memrealtime();
   }
 
-  // One pipeline step = iteration `it`.  PAR = it & 1 is a compile-time constant (two
-  // instantiations) so that the raw-stage offsets fold into the ds_read immediates; the
-  // filter stage (it % 3) is a run-time offset added to the two fragment base registers.
+  // One pipeline step = iteration `it`.  ONE instantiation: the raw stage that holds raw_{it+1}
+  // is selected by bit 15 of the eight patch base registers a_lo[] (R0 at 0, R1 at 32768; they
+  // are flipped after every iteration), the filter stage (it % 3) is a run-time offset added to
+  // the two fragment base registers, the DMA destinations are scalar.
   // The schedule inside is pinned with sched_barrier(0): left alone, hipcc sinks every
   // ds_read to just before its first use and the wave eats one LDS latency per point.
-  auto body = [&](auto par, int it, int us_cur, int us_nxt, int us_dma) {
-    constexpr int PAR = decltype(par)::value;
+  auto body = [&](int it, int rs_dma, int us_cur, int us_nxt, int us_dma) {
     if (ABLATE & 2048) { const unsigned long long t = stamp(); if (it) st_comp += t - st_prev; st_prev = t; }
     if (!(ABLATE & 8)) {
       wait_vmem_all();   // my DMA pieces of raw_{it+1} and U_{it+1} have landed
       __syncthreads();   // everyone's have; everyone is done with the stages refilled below
     }
     if (ABLATE & 2048) { const unsigned long long t = stamp(); st_wait += t - st_prev; st_prev = t; }
-    // The 8 LDS-DMA pieces this wave contributes per iteration (4 of raw_{it+2} into R[PAR], 4 of
+    // The 8 LDS-DMA pieces this wave contributes per iteration (4 of raw_{it+2} into R[it&1], 4 of
     // U_{it+2} into U[(it+2)%3]) are issued one per step in steps DMA0..DMA0+7 instead of in a
     // burst here: an LDS-DMA instruction holds the wave's issue port for >100 cycles, and
     // spread out the SIMD's other wave covers that with its MFMAs; starting at step 4 leaves the
     // last pieces a third of an iteration of flight time before the next vmcnt(0).
     const bool dma_on = it + 2 < L;
-    const char* rst = smem + (PAR ^ 1) * RAW_BYTES;   // raw_{it+1}
+    const bool dma_m0 = dma_on && w < 4, dma_m1 = dma_on && w >= 4;
+    (void)dma_m0; (void)dma_m1;
+    const char* rst = smem;   // raw_{it+1}: the stage is in a_lo[]
     const char* ucur0 = smem + b_base[0] + us_cur * U_BYTES;   // U_it
     const char* ucur1 = smem + b_base[1] + us_cur * U_BYTES;
     const char* unxt0 = smem + b_base[0] + us_nxt * U_BYTES;   // U_{it+1}
@@ -363,6 +394,17 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 16; e++) {
+#if WINO_PRIO == 1     // the younger wave of each SIMD (w >= 4) always ahead of the older one
+      if (e == 0) { if (w >= 4) __builtin_amdgcn_s_setprio(1); }
+#elif WINO_PRIO == 2   // mates lead half an iteration each
+      if (e == 0) { if (w >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      if (e == 8) { if (w >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#elif WINO_PRIO == 3   // mates lead alternate steps
+      if ((e & 1) == 0) { if (w >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      else { if (w >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#elif WINO_PRIO == 4   // mates lead alternate quarters
+      if ((e & 3) == 0) { if ((w >= 4) == (((e >> 2) & 1) == 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
       // -- top of the step: every LDS request of this step, before any MFMA.  Consumers sit
       //    at least one step later, so their waits are counted (lgkmcnt(N)), not drains.
       if (ABLATE & 64) {
@@ -376,11 +418,23 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
         bfn[e + PF - 16][0] = *(const f32x2*)(unxt0 + (e + PF - 16) * 2048);
         bfn[e + PF - 16][1] = *(const f32x2*)(unxt1 + (e + PF - 16) * 2048);
       }
+#if WINO_DMA_MODE == 0
       if (e >= DMA0 && e < DMA0 + 4) {
-        if (dma_on) issue_raw1(PAR, e - DMA0);
+        if (dma_on) issue_raw1(rs_dma, e - DMA0);
       } else if (e >= DMA0 + 4 && e < DMA0 + 8) {
         if (dma_on) issue_u1(us_dma, e - DMA0 - 4);
       }
+#else
+      // waves w and w+4 share a SIMD: they take alternate steps, two pieces each, so that a wave
+      // held up in the VMEM queue always has a mate with nothing but MFMAs to issue
+      if (e >= DMA0 && e < DMA0 + 8) {
+        const int kk = (e - DMA0) >> 1;   // 0,1: raw pairs; 2,3: filter pairs
+        if (((e - DMA0) & 1) == 0 ? dma_m0 : dma_m1) {
+          if (kk < 2) { issue_raw1(rs_dma, 2 * kk); issue_raw1(rs_dma, 2 * kk + 1); }
+          else { issue_u1(us_dma, 2 * (kk - 2)); issue_u1(us_dma, 2 * (kk - 2) + 1); }
+        }
+      }
+#endif
       // next iteration's A operand rides along: steps 0-7 read the patch (two pixels of patch
       // column e>>1 per step), steps 2,4,6,8 form B^T d column by column, steps 9-15 form
       // (B^T d) B in place over the points that have retired.  (After the last iteration this
@@ -393,130 +447,120 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       __builtin_amdgcn_sched_barrier(0);
       if (!(ABLATE & 96)) wait_lds(lds_wait_count(e));
       __builtin_amdgcn_sched_barrier(0);
-      if (e >= 2 && e <= 8 && (e & 1) == 0 && !(ABLATE & 32)) tmp_col(tmp, d, (e >> 1) - 1);
+      // (the empty asm statements pin the transform arithmetic to its step: without them the
+      //  optimizer sinks it out of the MFMA shadow towards the next iteration's first use)
+      if (e >= 2 && e <= 8 && (e & 1) == 0 && !(ABLATE & 32)) {
+        const int j = (e >> 1) - 1;
+        tmp_col(tmp, d, j);
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (WINO_PIN & 1) asm volatile("" : "+v"(tmp[i * 4 + j].x), "+v"(tmp[i * 4 + j].y));
+      }
       const P2 a = v[e];
       const f32x2 b0 = bf[e][0], b1 = bf[e][1];
       if (ABLATE & 4) {  // keep the operands live, skip the matrix pipe
         asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y));
       } else {
+#if WINO_MFMA_ASM
+        // Tied destination: the accumulate chain stays in place (same vDst as SrcC is the
+        // back-to-back form the matrix pipe forwards without wait states).  Left to the register
+        // allocator, the builtin form ping-pongs every accumulator through a temporary tuple
+        // (dst != SrcC), which costs the dependent MFMA several passes.  The compiler does not
+        // see MFMA hazards of inline asm: the only VALU access to acc[] is in the epilogue, behind
+        // explicit s_nops.
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][0]) : "v"(a.x), "v"(b0.x));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][1]) : "v"(a.x), "v"(b1.x));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][0]) : "v"(a.y), "v"(b0.y));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][1]) : "v"(a.y), "v"(b1.y));
+#else
         acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc[e][0], 0, 0, 0);
         acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc[e][1], 0, 0, 0);
         acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc[e][0], 0, 0, 0);
         acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc[e][1], 0, 0, 0);
+#endif
       }
       if (!(ABLATE & 32)) {
+        auto v_pinned = [&](int pt) {
+          v_point(v, tmp, pt);
+          if (WINO_PIN & 2) asm volatile("" : "+v"(v[pt].x), "+v"(v[pt].y));
+        };
         if (e >= 9 && e < 15) {  // points 2(e-9), 2(e-9)+1 < e have retired
-          v_point(v, tmp, 2 * (e - 9));
-          v_point(v, tmp, 2 * (e - 9) + 1);
+          v_pinned(2 * (e - 9));
+          v_pinned(2 * (e - 9) + 1);
         }
         if (e == 15) {
-          v_point(v, tmp, 12);
-          v_point(v, tmp, 13);
-          v_point(v, tmp, 14);
-          v_point(v, tmp, 15);
+          v_pinned(12);
+          v_pinned(13);
+          v_pinned(14);
+          v_pinned(15);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // ---- per-wave epilogue pieces (no LDS, no barrier: the DMA pipeline keeps running) ----------
+  // ---- per-wave epilogue (the DMA pipeline keeps running underneath) -------------------------
   // Slab image of one partial segment: [wave 0..7][q = 2r+cb][lane] of 16 B (the 2x2 output
   // pixels of tile row 4h+r, out-channel cb*16+t16, pre-BN).  Waves hand their 8 KiB parts over
   // independently: wave w of every segment of an item draws on tickets[8*item + w].
-  const unsigned slab_voff = (unsigned)((w * 8 * 64 + lane) * 16);
-  // all segments' parts of `item`, summed in segment order (bitwise reproducible whoever
-  // reduces); the item's segments belong to the non-empty workgroups among gA..gB
-  auto gather = [&](f32x4 (&y)[4][2], int gA, int gB) {
-    bool first = true;
-#pragma unroll 1
-    for (int g = gA; g <= gB; g++) {
-      if (sk_start(g + 1, sk_q, sk_rem, G) == sk_start(g, sk_q, sk_rem, G)) continue;   // owns nothing
-      const unsigned slot = 2u * (unsigned)g + (first ? 1u : 0u);
-      f32x4 t[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) t[q] = slab_load16(rsrc_slab, slab_voff + q * 1024, slot * SLAB_BYTES);
-#pragma unroll
-      for (int q = 0; q < 8; q++) y[q >> 1][q & 1] = first ? t[q] : y[q >> 1][q & 1] + t[q];
-      first = false;
-    }
-  };
-  // BN + ReLU, 4x4 quad transposes (lane (a,i) of a quad ends up with pixel i, out-channels
-  // 4a..4a+3), 16-byte stores into the padded NHWC output, zero ring next to edge tiles
-  // (the next 3x3 layer's padding, Kernel128_winograd.cu:163,243).
-  auto finalize = [&](int item, f32x4 (&y)[4][2]) {
-    if (ABLATE & 512) return;  // price the store tail
-    const int tb = item / KBLK, kb = item - tb * KBLK;
-    const int qi = t16 & 3, qa = t16 >> 2;
-    const bool b0 = qi & 1, b1 = qi & 2;
-    float sc[2], bi[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; cb++) {
-      const int kc = kb * KB + wk * 32 + cb * 16 + t16;
-      sc[cb] = bnScale[kc];
-      bi[cb] = bnBias[kc];
-    }
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int g = tb * TB + wt * 16 + 4 * h + r;
-      const bool live = g < totalTiles;
-      const TileCoord tc = decode_tile(live ? g : 0);
-      const int py = 1 + 2 * tc.ty + (qi >> 1), px = 1 + 2 * tc.tx + (qi & 1);
-      const unsigned kbyte = (unsigned)((kb * KB + wk * 32 + 4 * qa) * sizeof(float));
-      const unsigned img = (unsigned)(tc.n * WINO_HW * WINO_HW);
-      const unsigned o_main = (unsigned)((img + py * WINO_HW + px) * K * sizeof(float)) + kbyte;
-      // ring pixels adjacent to this lane's pixel
-      const bool rrow = live && (py == 1 || py == WINO_PQ), rcol = live && (px == 1 || px == WINO_PQ);
-      const int ry = py == 1 ? 0 : WINO_HW - 1, rx = px == 1 ? 0 : WINO_HW - 1;
-      const unsigned o_row = (unsigned)((img + ry * WINO_HW + px) * K * sizeof(float)) + kbyte;
-      const unsigned o_col = (unsigned)((img + py * WINO_HW + rx) * K * sizeof(float)) + kbyte;
-      const unsigned o_cor = (unsigned)((img + ry * WINO_HW + rx) * K * sizeof(float)) + kbyte;
-#pragma unroll
-      for (int cb = 0; cb < 2; cb++) {
-        f32x4 val;
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-          float v1 = sc[cb] * y[r][cb][p] + bi[cb];
-          if (relu) v1 = fmaxf(v1, 0.f);
-          val[p] = v1;
-        }
-        val = quad_transpose(val, b0, b1);
-        const unsigned so = (unsigned)(cb * 16 * sizeof(float));
-        if (live) buf_store16(val, rsrc_out, o_main, so);
-        if (rrow) buf_store16(zero4, rsrc_out, o_row, so);
-        if (rcol) buf_store16(zero4, rsrc_out, o_col, so);
-        if (rrow && rcol) buf_store16(zero4, rsrc_out, o_cor, so);
-      }
-    }
-  };
-  auto draw_ticket = [&](int item) -> unsigned {   // one returning agent-scope add per wave
-    unsigned old = 0;
-    if (lane == 0)
-      old = __hip_atomic_fetch_add(tickets + (size_t)item * 8 + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return old;   // meaningful in lane 0; readfirstlane at the use
-  };
-  // which logical workgroups share `item` (one this workgroup works on): walk outwards from lg.
-  // With more workgroups than iterations some own nothing; they are not segments.
-  auto item_segments = [&](int item, int& gA, int& gB, int& nseg) {
-    const unsigned x0 = (unsigned)item * (unsigned)nchunks, x1 = x0 + nchunks - 1;
-    int a = lg, b = lg;
-    while (sk_start(a, sk_q, sk_rem, G) > x0) a--;
-    while (b + 1 < G && sk_start(b + 1, sk_q, sk_rem, G) <= x1) b++;
-    int n = 0;
-    for (int g = a; g <= b; g++)
-      n += sk_start(g + 1, sk_q, sk_rem, G) != sk_start(g, sk_q, sk_rem, G);
-    gA = a;
-    gB = b;
-    nseg = n;
-  };
-
+  //
   // A segment ends with the item's last chunk or with the range.  Whole segments are finalized
   // from registers.  A partial segment publishes its slab part; if more work follows (it is the
-  // head of the range) its ticket is drawn one segment later, when the stores have long drained
-  // and registers are free again; the range's last segment draws at once.  Whoever draws an
-  // item's last ticket gathers all parts and finalizes.
-  auto epilogue = [&](bool last_of_range) {
+  // head of the range) its ticket is drawn one segment later, when the stores have long drained;
+  // the range's last segment draws at once.  Whoever draws an item's last ticket gathers all
+  // parts (in segment order: bitwise reproducible whoever reduces) and finalizes.
+  //
+  // Everything the epilogue needs beyond the accumulators is re-derived here from an OPAQUE copy
+  // of the lane / wave id and from the kernarg segment, so that nothing epilogue-only is hoisted
+  // out of the segment loop and kept in registers across the main loop (which has none to spare).
+  // rfree / ufree = byte offsets of the two LDS stages nobody needs at a segment boundary
+  // (raw_{it+1} is already in registers, U_it is spent); each wave takes 8 KiB of them.
+  auto epilogue = [&](bool last_of_range, int rfree, int ufree) {
+    unsigned long long ph_t = 0;
+    auto phase = [&](int k) { if (ABLATE & 2048) { const unsigned long long t = stamp(); if (k >= 0) st_ph[k] += t - ph_t; ph_t = t; } };
+    phase(-1);
+    // every wave is done reading those two stages (a bare barrier: no memory counter needs to
+    // drain here, and __syncthreads() would wait for the LDS-DMA pieces in flight)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the last MFMAs' results must have landed before VALU code reads / rewrites the accumulators
+    // (the hazard recognizer cannot see through the inline-asm MFMAs)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    phase(0);
+    int ln = lane, wv = w;
+    asm volatile("" : "+v"(ln));
+    asm volatile("" : "+s"(wv));
+    const int e_t16 = ln & 15, e_h = ln >> 4, e_wt = wv >> 1, e_wk = wv & 1;
+    char* wreg = smem + (wv < 4 ? rfree + wv * 8192 : ufree + (wv - 4) * 8192);
+    // (constant address space: scalar loads, so the descriptors stay in SGPRs)
+    typedef const __attribute__((address_space(4))) FusedParams* KernargPtr;
+    KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const float* bnBias = kp->bnBias;
+    const float* bnScale = kp->bnScale;
+    unsigned* tickets = kp->tickets;
+    const auto rsrc_out = make_rsrc(kp->out, (unsigned)((size_t)N * WINO_HW * WINO_HW * K * sizeof(float)));
+    const auto rsrc_slab = make_rsrc(kp->slabs, (unsigned)((size_t)2 * G * SLAB_BYTES));
+    const unsigned slab_voff = (unsigned)((wv * 8 * 64 + ln) * 16);
+
+    auto load_bn = [&](int item, float (&sc)[2], float (&bi)[2]) {
+      const int kb = item % KBLK;
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++) {
+        const int kc = kb * KB + e_wk * 32 + cb * 16 + e_t16;
+        sc[cb] = bnScale[kc];
+        bi[cb] = bnBias[kc];
+      }
+    };
+    auto draw_ticket = [&](int item) -> unsigned {   // one returning agent-scope add per wave
+      unsigned old = 0;
+      if (ln == 0)
+        old = __hip_atomic_fetch_add(tickets + (size_t)item * 8 + wv, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return old;   // meaningful in lane 0; readfirstlane at the use
+    };
+
+    // folded BN of this segment's item (this lane's two out-channels); in flight during A^T m A
+    float bn_sc[2], bn_bi[2];
+    load_bn(c_item, bn_sc, bn_bi);
     unsigned pend_old = 0;
     if (pend_item >= 0) pend_old = draw_ticket(pend_item);   // in flight while A^T m A runs
     // A^T m A (C/D layout: col = lane&15, row = 4*(lane>>4)+r):
@@ -545,6 +589,7 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       acc[e][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc[e][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    phase(1);
     const bool whole = seg_c0 == 0 && c_chunk == nchunks - 1;
     // up to two items to look at: [0] this segment's, [1] the deferred head segment's
     int job0 = -1, job1 = -1;
@@ -552,6 +597,8 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     if (whole) {
       job0 = c_item;
     } else if (!(ABLATE & 1024)) {
+      // slab slot: 2l for the segment that continues an item (head of l's range), 2l+1 for the
+      // one that starts an item
       const unsigned my_slot = 2u * lg + (seg_c0 == 0 ? 1u : 0u);
 #pragma unroll
       for (int q = 0; q < 8; q++)
@@ -568,52 +615,131 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       job1 = pend_item;
       pend_item = -1;
     }
+    phase(2);
 #pragma unroll 1
     for (int j = 0; j < 2; j++) {
       const int item = j == 0 ? job0 : job1;
       if (item < 0) continue;
       if (!(j == 0 && whole)) {
-        int gA, gB, nseg;
-        item_segments(item, gA, gB, nseg);
+        // which logical workgroups share `item`: walk outwards from lg.  With more workgroups
+        // than iterations some own nothing; they are not segments.
+        const unsigned x0 = (unsigned)item * (unsigned)nchunks, x1 = x0 + nchunks - 1;
+        int gA = lg, gB = lg;
+        while (sk_start(gA, sk_q, sk_rem, G) > x0) gA--;
+        while (gB + 1 < G && sk_start(gB + 1, sk_q, sk_rem, G) <= x1) gB++;
+        int nseg = 0;
+        for (int g = gA; g <= gB; g++)
+          nseg += sk_start(g + 1, sk_q, sk_rem, G) != sk_start(g, sk_q, sk_rem, G);
         const unsigned old = __builtin_amdgcn_readfirstlane(j == 0 ? old0 : pend_old);
         if (old != (unsigned)(nseg - 1)) continue;   // another workgroup's wave w will finish the item
-        if (lane == 0)   // self-cleaning counter: the next launch finds 0 again
-          __hip_atomic_store(tickets + (size_t)item * 8 + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gather(y, gA, gB);
+        if (ln == 0)   // self-cleaning counter: the next launch finds 0 again
+          __hip_atomic_store(tickets + (size_t)item * 8 + wv, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // gather: all segments' parts, summed in segment order
+        bool first = true;
+#pragma unroll 1
+        for (int g = gA; g <= gB; g++) {
+          if (sk_start(g + 1, sk_q, sk_rem, G) == sk_start(g, sk_q, sk_rem, G)) continue;   // owns nothing
+          const unsigned slot = 2u * (unsigned)g + (first ? 1u : 0u);
+          f32x4 t[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) t[q] = slab_load16(rsrc_slab, slab_voff + q * 1024, slot * SLAB_BYTES);
+#pragma unroll
+          for (int q = 0; q < 8; q++) y[q >> 1][q & 1] = first ? t[q] : y[q >> 1][q & 1] + t[q];
+          first = false;
+        }
       }
-      finalize(item, y);
+      float sc2[2] = {bn_sc[0], bn_sc[1]}, bi2[2] = {bn_bi[0], bn_bi[1]};
+      if (item != c_item) load_bn(item, sc2, bi2);   // the deferred head item
+      if (ABLATE & 512) continue;  // price the store tail
+
+      // ---- finalize: BN + ReLU, then the wave's 16 tiles x 2x2 px x 32 out-channels go through
+      // its private 8 KiB of LDS so that they leave as whole 128-byte runs of the padded NHWC
+      // output (16 B per lane, 8 runs per store); plus the zero ring next to edge tiles (the next
+      // 3x3 layer's padding, Kernel128_winograd.cu:163,243).
+      // Image: [tile 0..15][px 0..3][k 0..31] floats; the 16-float group index (2*px + cb) is
+      // XORed with (tile>>2)&3 = the MFMA row group h, which makes the ds_write_b32 of the 4 row
+      // groups and the ds_read_b128 of every 16 lanes hit 64 distinct banks.
+      const int tb = item / KBLK, kb = item - tb * KBLK;
+      int ep_wbase[4], ep_rbase[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        ep_wbase[jj] = e_h * 2048 + ((jj ^ e_h) << 6) + e_t16 * 4;                       // + r*512 + (g>>2)*256
+        const int px = (ln >> 3) & 3, c = ln & 7;
+        ep_rbase[jj] = (ln >> 5) * 512 + (((px * 2 + (c >> 2)) ^ jj) << 6) + (c & 3) * 16;   // + 2i*512
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+#pragma unroll
+          for (int pp = 0; pp < 4; pp++) {
+            float v1 = sc2[cb] * y[r][cb][pp] + bi2[cb];
+            if (relu) v1 = fmaxf(v1, 0.f);
+            const int g = pp * 2 + cb;
+            *(float*)(wreg + ep_wbase[g & 3] + r * 512 + (g >> 2) * 256) = v1;
+          }
+        }
+      }
+      // lane -> run (lane>>3) = (tile 2i + (lane>>5), px (lane>>3)&3), 16-byte chunk lane&7
+      // (tried: the tile arithmetic on the scalar unit, one tile per half-wave -- 40 % slower)
+      const int px = (ln >> 3) & 3, pa = px >> 1, pb = px & 1;
+      const unsigned kbyte = (unsigned)((kb * KB + e_wk * 32 + (ln & 7) * 4) * sizeof(float));
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const f32x4 val = *(const f32x4*)(wreg + ep_rbase[i >> 1] + i * 1024);
+        const int g = tb * TB + e_wt * 16 + 2 * i + (ln >> 5);
+        const bool live = g < totalTiles;
+        const TileCoord tc = decode_tile(live ? g : 0);
+        const int py = 1 + 2 * tc.ty + pa, pxx = 1 + 2 * tc.tx + pb;
+        const unsigned img = (unsigned)(tc.n * WINO_HW * WINO_HW);
+        if (live) buf_store16(val, rsrc_out, (unsigned)((img + py * WINO_HW + pxx) * K * sizeof(float)) + kbyte, 0);
+        // ring duties of this lane's pixel: the ring pixel above/below it, the one left/right of
+        // it; in the four corner tiles the inner pixel (no other duty) takes the corner
+        const bool top = tc.ty == 0, bot = tc.ty == 6, lef = tc.tx == 0, rig = tc.tx == 6;
+        const bool rrow = live && ((top && pa == 0) || (bot && pa == 1));
+        const bool rcol = live && ((lef && pb == 0) || (rig && pb == 1));
+        const bool rcor = live && (top || bot) && (lef || rig) && pa == (top ? 1 : 0) && pb == (lef ? 1 : 0);
+        const int ry = top ? 0 : WINO_HW - 1, rx = lef ? 0 : WINO_HW - 1;
+        if (rrow || rcor)
+          buf_store16(zero4, rsrc_out, (unsigned)((img + ry * WINO_HW + (rcor ? rx : pxx)) * K * sizeof(float)) + kbyte, 0);
+        if (rcol)
+          buf_store16(zero4, rsrc_out, (unsigned)((img + py * WINO_HW + rx) * K * sizeof(float)) + kbyte, 0);
+      }
     }
+    phase(3);
   };
 
   // ================================ main loop =====================================
+  // Per segment: the tight loop over its iterations, then the one epilogue site.
   {
     int us = 0;  // filter stage of iteration `it` (= it % 3)
     auto next = [](int s) { return s == 2 ? 0 : s + 1; };
-    // after the MFMAs of iteration `it`: move the DMA stream on; close the segment if it ends here
-    auto post = [&](int it) {
-      if (it + 2 < L) dma_advance();
-      const bool last_of_range = it == L - 1;
-      if (c_chunk == nchunks - 1 || last_of_range) {
-        if (ABLATE & 2048) st_comp += stamp() - st_prev;
-        epilogue(last_of_range);
-        if (ABLATE & 2048) st_prev = stamp();
-        c_item++;
-        c_chunk = 0;
-        seg_c0 = 0;
-      } else {
-        c_chunk++;
-      }
-    };
+    int it = 0;
 #pragma unroll 1
-    for (int it = 0; it < L; it += 2) {
-      body(std::integral_constant<int, 0>{}, it, us, next(us), next(next(us)));
-      us = next(us);
-      post(it);
-      if (it + 1 < L) {
-        body(std::integral_constant<int, 1>{}, it + 1, us, next(us), next(next(us)));
+    for (;;) {
+      const int n = nchunks - c_chunk < L - it ? nchunks - c_chunk : L - it;   // iterations of this segment
+      c_chunk += n - 1;                                                         // its last chunk
+      int us_last = us;
+#pragma unroll 1
+      for (int k = 0; k < n; k++) {
+        body(it, it & 1, us, next(us), next(next(us)));
+#pragma unroll
+        for (int p = 0; p < 8; p++) a_lo[p] ^= RAW_BYTES;
+        if (it + 2 < L) dma_advance();
+        us_last = us;
         us = next(us);
-        post(it + 1);
+        it++;
       }
+      // the segment's last iteration was it-1: raw stage R[it & 1] and filter stage U[us_last] are free
+      const bool last_of_range = it == L;
+      if (ABLATE & 2048) { const unsigned long long t = stamp(); st_comp += t - st_prev; st_prev = t; }
+      epilogue(last_of_range, (it & 1) * RAW_BYTES, N_RSTAGE * RAW_BYTES + us_last * U_BYTES);
+      if (ABLATE & 2048) { const unsigned long long t = stamp(); st_epi += t - st_prev; st_prev = t; }
+      if (last_of_range) break;
+      c_item++;
+      c_chunk = 0;
+      seg_c0 = 0;
     }
   }
 #undef A_OFF
@@ -621,10 +747,15 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   // diagnostic builds: stamps go past the N images of `out` (the tool allocates that room)
   if (ABLATE & 2048) {
     if (lane == 0) {
-      unsigned long long* dbg = (unsigned long long*)(out + (size_t)N * WINO_HW * WINO_HW * K) +
-                                ((size_t)lg * 8 + w) * 2;
+      unsigned long long* dbg = (unsigned long long*)(prm.out + (size_t)N * WINO_HW * WINO_HW * K) +
+                                ((size_t)lg * 8 + w) * 8;
       dbg[0] = st_wait;
       dbg[1] = st_comp;
+      dbg[2] = st_epi;
+      dbg[3] = st_ph[0];
+      dbg[4] = st_ph[1];
+      dbg[5] = st_ph[2];
+      dbg[6] = st_ph[3];
     }
   }
   if (ABLATE & 16) {
@@ -632,7 +763,7 @@ wino_f2_fused_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     stamp_r += __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
       unsigned long long* dbg =
-          (unsigned long long*)(out + (size_t)N * WINO_HW * WINO_HW * K) + (size_t)lg * 2;
+          (unsigned long long*)(prm.out + (size_t)N * WINO_HW * WINO_HW * K) + (size_t)lg * 2;
       dbg[0] = stamp_c;
       dbg[1] = stamp_r;
     }

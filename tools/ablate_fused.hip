@@ -29,14 +29,15 @@ float run(const float* in, const float* U, const float* b, const float* s, float
   const int grid = grid_for(N, K);
   CK(hipMemset(g_tickets, 0, 65536 * 4));   // ablated variants may leave tickets behind
   const unsigned T = (unsigned)nTB * (K / KB) * (C / 8);
+  const FusedParams prm = {in, U, N, C, K, 1, nTB, T / grid, T % grid, b, s, out, g_slabs, g_tickets};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; i++)
-    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB, g_slabs, g_tickets, T / grid, T % grid);
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < reps; i++)
-    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, in, U, b, s, out, N, C, K, 1, nTB, g_slabs, g_tickets, T / grid, T % grid);
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -59,16 +60,43 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(U, h.data(), (size_t)16 * C * K * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b, h.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + K, K * 4, hipMemcpyHostToDevice));
+  if (argc > 3) {  // quick mode: just the product kernel at N = 128, three trials of 50 launches
+    float t[3];
+    for (int i = 0; i < 3; i++) t[i] = run<0>(in, U, b, s, out, 128, C, K, 50);
+    std::sort(t, t + 3);
+    const int nTB = (128 * 49 + TB - 1) / TB, wgs = grid_for(128, K);
+    const double iters = (double)nTB * (K / KB) * (C / 8) / wgs;
+    run<16>(in, U, b, s, out, 128, C, K, 3);
+    std::vector<unsigned long long> st((size_t)wgs * 2);
+    CK(hipMemcpy(st.data(), out + (size_t)128 * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, rt = 0, cmax = 0;
+    for (int i = 0; i < wgs; i++) { cyc += st[2 * i]; rt += st[2 * i + 1]; cmax = std::max(cmax, (double)st[2 * i]); }
+    printf("%s C=%d grid=%d: %.1f / %.1f / %.1f us   loop+epilogues: %.1f cycles per MFMA per SIMD (slowest workgroup %.1f) at %.3f GHz\n",
+           argv[0], C, wgs, t[0], t[1], t[2], cyc / wgs / iters / 128.0, cmax / iters / 128.0, cyc / rt * 0.1);
+    return 0;
+  }
   printf("C=K=%d   us per launch; items = K/64 * ceil(N*49/64); grid = %d logical workgroups (0: one item each)\n", C, g_grid);
-  printf("%6s %6s %6s | %8s %8s %8s %8s %8s %8s %8s %8s\n", "N", "items", "grid", "full", "noRawDMA", "noUDMA", "noDMA", "noMFMA",
-         "noBarr", "noStore", "noSlab");
+  printf("%6s %6s %6s | %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s\n", "N", "items", "grid", "full", "noRawDMA", "noUDMA", "noDMA", "noMFMA",
+         "noBarr", "noStore", "noSlab", "noA", "noB");
   for (int N : Ns) {
     const int items = (K / 64) * ((N * 49 + 63) / 64);
-    printf("%6d %6d %6d | %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f\n", N, items, grid_for(N, K),
+    printf("%6d %6d %6d | %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f\n", N, items, grid_for(N, K),
            run<0>(in, U, b, s, out, N, C, K, 20), run<1>(in, U, b, s, out, N, C, K, 20),
            run<2>(in, U, b, s, out, N, C, K, 20), run<3>(in, U, b, s, out, N, C, K, 20),
            run<4>(in, U, b, s, out, N, C, K, 20), run<8>(in, U, b, s, out, N, C, K, 20),
-           run<512>(in, U, b, s, out, N, C, K, 20), run<1024>(in, U, b, s, out, N, C, K, 20));
+           run<512>(in, U, b, s, out, N, C, K, 20), run<1024>(in, U, b, s, out, N, C, K, 20),
+           run<32>(in, U, b, s, out, N, C, K, 20), run<64>(in, U, b, s, out, N, C, K, 20));
+  }
+  {  // what the non-MFMA side costs on its own (N = 128): everything below skips the MFMAs
+    const int N = 128;
+    printf("noMFMA and ... : alone %.1f  noDMA %.1f  noBarr %.1f  noA %.1f  noB %.1f  noA+noB %.1f  noDMA+noA+noB %.1f  noDMA+noBarr+noA+noB %.1f  +noStore+noSlab %.1f\n",
+           run<4>(in, U, b, s, out, N, C, K, 20), run<4 | 3>(in, U, b, s, out, N, C, K, 20), run<4 | 8>(in, U, b, s, out, N, C, K, 20),
+           run<4 | 32>(in, U, b, s, out, N, C, K, 20), run<4 | 64>(in, U, b, s, out, N, C, K, 20), run<4 | 96>(in, U, b, s, out, N, C, K, 20),
+           run<4 | 96 | 3>(in, U, b, s, out, N, C, K, 20), run<4 | 96 | 3 | 8>(in, U, b, s, out, N, C, K, 20),
+           run<4 | 96 | 3 | 8 | 512 | 1024>(in, U, b, s, out, N, C, K, 20));
+    printf("MFMA and ...   : noDMA+noBarr %.1f  noDMA+noBarr+noA+noB %.1f  +noStore+noSlab %.1f\n",
+           run<3 | 8>(in, U, b, s, out, N, C, K, 20), run<3 | 8 | 96>(in, U, b, s, out, N, C, K, 20),
+           run<3 | 8 | 96 | 512 | 1024>(in, U, b, s, out, N, C, K, 20));
   }
   {  // in-kernel clock of the main loop (diagnostic build, ABLATE bit 16)
     const int N = 128;
@@ -87,14 +115,15 @@ int main(int argc, char** argv) {
     const int nTB = (N * 49 + TB - 1) / TB, wgs = grid_for(N, K);
     const double iters = (double)nTB * (K / KB) * (C / 8) / wgs;
     run<2048>(in, U, b, s, out, N, C, K, 2);
-    std::vector<unsigned long long> st((size_t)wgs * 16);
+    std::vector<unsigned long long> st((size_t)wgs * 64);
     CK(hipMemcpy(st.data(), out + (size_t)N * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
-    double wsum[8] = {0}, csum[8] = {0};
-    for (int i = 0; i < wgs; i++) for (int w = 0; w < 8; w++) { wsum[w] += st[(i * 8 + w) * 2]; csum[w] += st[(i * 8 + w) * 2 + 1]; }
+    double sum[8][7] = {{0}};
+    for (int i = 0; i < wgs; i++) for (int w = 0; w < 8; w++) for (int k = 0; k < 7; k++) sum[w][k] += st[(i * 8 + w) * 8 + k];
     printf("per chunk iteration (%.2f per workgroup), mean over %d workgroups; stamps add overhead, read the SHARES:\n", iters, wgs);
     for (int w = 0; w < 8; w++)
-      printf("  wave %d: wait(vmcnt+barrier) %7.0f cycles  compute %7.0f cycles  wait share %.1f%%\n", w,
-             wsum[w] / wgs / iters, csum[w] / wgs / iters, 100.0 * wsum[w] / (wsum[w] + csum[w]));
+      printf("  wave %d: wait(vmcnt+barrier) %6.0f  compute %6.0f cycles per iteration (wait share %4.1f%%) | epilogues per workgroup %7.0f cycles = barrier %6.0f + AtmA %6.0f + slab/ticket %6.0f + gather/finalize %6.0f\n", w,
+             sum[w][0] / wgs / iters, sum[w][1] / wgs / iters, 100.0 * sum[w][0] / (sum[w][0] + sum[w][1]), sum[w][2] / wgs,
+             sum[w][3] / wgs, sum[w][4] / wgs, sum[w][5] / wgs, sum[w][6] / wgs);
   }
   return 0;
 }
