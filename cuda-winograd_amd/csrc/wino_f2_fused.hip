@@ -226,21 +226,41 @@ static int sk_workspace(int dev, hipStream_t s, int G, size_t items, float** sla
   return WINO_OK;
 }
 
-// Launch geometry of the throughput kernel: G logical workgroups (a multiple of 8, at most one per
-// CU) share T = items * C/8 chunk iterations evenly; small launches keep at least SK_MIN_ITERS
-// iterations per workgroup so that the slab hand-off stays a small part of a workgroup's work.
+// Launch geometry of the throughput kernel: G logical workgroups share T = items * C/8 chunk
+// iterations evenly (stream-K).  Two candidates are priced with a small cost model, in units of one
+// chunk iteration (~2.2 us at 2.3 GHz):
+//   * G = items: every workgroup owns whole items, no hand-off; with more items than CUs the
+//     hardware runs ceil(items / CUs) rounds;
+//   * G = CUs (capped so that a workgroup keeps >= SK_MIN_ITERS iterations): one round, every CU
+//     gets T/G iterations, but a range cuts items -> about one more epilogue per workgroup and
+//     the slab hand-off.
+// Measured on MI355X (N = 128): 256 channels 392 items -> stream-K 136 us vs 156 us; 128 channels
+// 196 items -> whole items 44 us vs 54 us.  An epilogue costs ~2.3 iterations, the hand-off
+// (drain, ticket, gather of the range's last segment) ~4.8.
 constexpr int SK_MIN_ITERS = 8;
-static int sk_grid(int dev, long long T, int* G) {
+constexpr double SK_EPILOGUE_ITERS = 2.3, SK_HANDOFF_ITERS = 4.8;
+static double sk_cost(long long items, int nchunks, int cus, long long G) {
+  const long long T = items * nchunks;
+  const long long per = (T + G - 1) / G;
+  const long long rounds = (G + cus - 1) / cus;
+  const bool aligned = items % G == 0;   // every range is a whole number of items
+  const double nseg = (double)((per + nchunks - 1) / nchunks) + (aligned ? 0.0 : 1.0);
+  return (double)rounds * ((double)per + nseg * SK_EPILOGUE_ITERS + (aligned ? 0.0 : SK_HANDOFF_ITERS));
+}
+static int sk_grid(int dev, long long items, int nchunks, int* G) {
   int cus = 0;
   if (int rc = sk_cus(dev, &cus)) return rc;
   const char* g_env = getenv("WINO_SK_GRID");        // developer overrides, read per call so that
   const char* m_env = getenv("WINO_SK_MIN_ITERS");   // tests can sweep the decomposition
   const int min_iters = m_env && atoi(m_env) > 0 ? atoi(m_env) : SK_MIN_ITERS;
-  long long g = cus & ~7;
-  if (g < 8) g = 8;
-  const long long cap = (T / min_iters) & ~7ll;
-  if (g > cap) g = cap < 8 ? 8 : cap;
-  if (g_env && atoi(g_env) >= 8) g = atoi(g_env) & ~7;
+  const long long T = items * nchunks;
+  long long g_sk = cus;
+  if (g_sk > T / min_iters) g_sk = T / min_iters;
+  if (g_sk < 1) g_sk = 1;
+  long long g = g_sk;
+  if (items <= 65535 && sk_cost(items, nchunks, cus, items) <= sk_cost(items, nchunks, cus, g_sk)) g = items;
+  if (g_env && atoi(g_env) >= 1) g = atoi(g_env);
+  if (g > 65535) g = 65535;
   *G = (int)g;
   return WINO_OK;
 }
@@ -282,7 +302,7 @@ int wino_conv3x3_prepare(int N, int C, int K, wino_stream_t s) {
   const int nTB = (N * WINO_TILES + TB - 1) / TB;
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;
-  if (int rc = sk_grid(dev, (long long)items * (C / BC), &G)) return rc;
+  if (int rc = sk_grid(dev, (long long)items, C / BC, &G)) return rc;
   float* slabs;
   unsigned* tickets;
   return sk_workspace(dev, (hipStream_t)s, G, items, &slabs, &tickets);
@@ -311,7 +331,7 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
   }
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;
-  if (int rc = sk_grid(dev, (long long)items * (C / BC), &G)) return rc;
+  if (int rc = sk_grid(dev, (long long)items, C / BC, &G)) return rc;
   float* slabs = nullptr;
   unsigned* tickets = nullptr;
   if (int rc = sk_workspace(dev, (hipStream_t)s, G, items, &slabs, &tickets)) return rc;

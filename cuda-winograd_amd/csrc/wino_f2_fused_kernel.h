@@ -48,6 +48,9 @@ constexpr int DMA0 = WINO_DMA0;              // first point-step that issues an 
 #ifndef WINO_PRIO
 #define WINO_PRIO 0
 #endif
+#ifndef WINO_XF_PACKED
+#define WINO_XF_PACKED 1
+#endif
 #ifndef WINO_PIN
 #define WINO_PIN 0
 #endif
@@ -157,15 +160,43 @@ wino_f2_fused_kernel(const FusedParams prm) {
 
   // XCD-aware block -> logical workgroup: blocks b and b+8 share an XCD (its L2), so consecutive
   // logical workgroups -- which walk consecutive items, i.e. the K/64 k-blocks that read the same
-  // input tiles -- are placed on the same XCD.  gridDim.x is a multiple of 8.
+  // input tiles -- are placed on the same XCD: XCD x = blockIdx % 8 gets the logical range that
+  // starts at x*(G/8) + min(x, G%8).
   const int KBLK = K >> 6;
   const int nchunks = C / BC;
   const int G = gridDim.x;
-  const int lg = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int lg = (int)(blockIdx.x & 7) * (G >> 3) + ((int)(blockIdx.x & 7) < (G & 7) ? (int)(blockIdx.x & 7) : (G & 7)) +
+                 (int)(blockIdx.x >> 3);
   // T = nTB * KBLK * nchunks = sk_q * G + sk_rem chunk iterations in all
   const unsigned i_begin = sk_start(lg, sk_q, sk_rem, G);
   const int L = (int)(sk_start(lg + 1, sk_q, sk_rem, G) - i_begin);   // chunk iterations of this workgroup
-  if (L <= 0) return;
+
+  // ---- ring pass: the output's zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:
+  // 163,243) is written here, once per launch, as a flat list of 16-byte units -- N images x 60
+  // ring pixels x K/4 units -- split evenly over the workgroups; the stores are fully coalesced
+  // and drain while the first LDS-DMA pieces are in flight.  (Per tile in the epilogue, the ring
+  // cost more than the tiles' own stores: sparse predicated stores and their address arithmetic.)
+  auto ring_pass = [&]() {
+    if (ABLATE & 512) return;
+    const unsigned upp = (unsigned)K >> 2;                       // units per ring pixel
+    const unsigned long long U = (unsigned long long)N * 60u * upp;
+    const unsigned u_begin = (unsigned)(U * (unsigned)lg / (unsigned)G);
+    const unsigned u_end = (unsigned)(U * ((unsigned)lg + 1u) / (unsigned)G);
+    const auto rsrc_ring = make_rsrc(prm.out, (unsigned)((size_t)N * WINO_HW * WINO_HW * K * sizeof(float)));
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned u = u_begin + threadIdx.x; u < u_end; u += NTHREADS) {
+      const unsigned pid = u / upp, unit = u - pid * upp;
+      const unsigned n = pid / 60u, q = pid - n * 60u;
+      // q: 0..15 row 0, 16..31 row 15, 32..45 column 0 (rows 1..14), 46..59 column 15
+      const unsigned y = q < 16 ? 0u : q < 32 ? (unsigned)(WINO_HW - 1) : q < 46 ? q - 31u : q - 45u;
+      const unsigned x = q < 16 ? q : q < 32 ? q - 16u : q < 46 ? 0u : (unsigned)(WINO_HW - 1);
+      buf_store16(zero4, rsrc_ring, (((n * WINO_HW + y) * WINO_HW + x) * (unsigned)K + unit * 4u) * (unsigned)sizeof(float), 0);
+    }
+  };
+  if (L <= 0) {   // more workgroups than iterations: this one only has its share of the ring
+    ring_pass();
+    return;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -207,6 +238,13 @@ wino_f2_fused_kernel(const FusedParams prm) {
   // Written per component: with WINO_SCALAR_XFORM the build passes -fno-slp-vectorize so that
   // these stay v_add_f32/v_sub_f32 instead of v_pk_add_f32 (packed f32 VALU next to MFMAs
   // measured slower than two plain ops on this chip).
+#if WINO_XF_PACKED
+  typedef f32x2 P2;   // two channels as a register pair: v_pk_add_f32
+  auto sub2 = [](const P2& a, const P2& b) { return a - b; };
+  auto add2 = [](const P2& a, const P2& b) { return a + b; };
+  auto ld2 = [](const char* p) { return *(const f32x2*)p; };
+#define PIN2(val) asm volatile("" : "+v"(val))
+#else
   struct P2 { float x, y; };  // two channels, deliberately NOT a vector type
   auto sub2 = [](const P2& a, const P2& b) { P2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; };
   auto add2 = [](const P2& a, const P2& b) { P2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; };
@@ -220,6 +258,8 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #endif
     return r;
   };
+#define PIN2(val) asm volatile("" : "+v"((val).x), "+v"((val).y))
+#endif
   auto tmp_col = [&](P2* tmp, const P2* d, int j) {  // B^T d, column j
     tmp[0 * 4 + j] = sub2(d[0 * 4 + j], d[2 * 4 + j]);
     tmp[1 * 4 + j] = add2(d[1 * 4 + j], d[2 * 4 + j]);
@@ -328,6 +368,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #pragma unroll
   for (int j = 0; j < 4; j++) issue_u1(0, j);
   dma_advance();
+  ring_pass();   // in the shadow of the first pieces' flight
   if (!(ABLATE & 8)) {
     wait_vmem_all();
     __syncthreads();
@@ -453,7 +494,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
         const int j = (e >> 1) - 1;
         tmp_col(tmp, d, j);
 #pragma unroll
-        for (int i = 0; i < 4; i++) if (WINO_PIN & 1) asm volatile("" : "+v"(tmp[i * 4 + j].x), "+v"(tmp[i * 4 + j].y));
+        for (int i = 0; i < 4; i++) if (WINO_PIN & 1) PIN2(tmp[i * 4 + j]);
       }
       const P2 a = v[e];
       const f32x2 b0 = bf[e][0], b1 = bf[e][1];
@@ -481,7 +522,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
       if (!(ABLATE & 32)) {
         auto v_pinned = [&](int pt) {
           v_point(v, tmp, pt);
-          if (WINO_PIN & 2) asm volatile("" : "+v"(v[pt].x), "+v"(v[pt].y));
+          if (WINO_PIN & 2) PIN2(v[pt]);
         };
         if (e >= 9 && e < 15) {  // points 2(e-9), 2(e-9)+1 < e have retired
           v_pinned(2 * (e - 9));
@@ -654,8 +695,8 @@ wino_f2_fused_kernel(const FusedParams prm) {
 
       // ---- finalize: BN + ReLU, then the wave's 16 tiles x 2x2 px x 32 out-channels go through
       // its private 8 KiB of LDS so that they leave as whole 128-byte runs of the padded NHWC
-      // output (16 B per lane, 8 runs per store); plus the zero ring next to edge tiles (the next
-      // 3x3 layer's padding, Kernel128_winograd.cu:163,243).
+      // output (16 B per lane, 8 runs per store).  (The zero ring is written by the ring pass at
+      // the start of the kernel.)
       // Image: [tile 0..15][px 0..3][k 0..31] floats; the 16-float group index (2*px + cb) is
       // XORed with (tile>>2)&3 = the MFMA row group h, which makes the ds_write_b32 of the 4 row
       // groups and the ds_read_b128 of every 16 lanes hit 64 distinct banks.
@@ -684,7 +725,6 @@ wino_f2_fused_kernel(const FusedParams prm) {
       // (tried: the tile arithmetic on the scalar unit, one tile per half-wave -- 40 % slower)
       const int px = (ln >> 3) & 3, pa = px >> 1, pb = px & 1;
       const unsigned kbyte = (unsigned)((kb * KB + e_wk * 32 + (ln & 7) * 4) * sizeof(float));
-      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const f32x4 val = *(const f32x4*)(wreg + ep_rbase[i >> 1] + i * 1024);
@@ -694,17 +734,6 @@ wino_f2_fused_kernel(const FusedParams prm) {
         const int py = 1 + 2 * tc.ty + pa, pxx = 1 + 2 * tc.tx + pb;
         const unsigned img = (unsigned)(tc.n * WINO_HW * WINO_HW);
         if (live) buf_store16(val, rsrc_out, (unsigned)((img + py * WINO_HW + pxx) * K * sizeof(float)) + kbyte, 0);
-        // ring duties of this lane's pixel: the ring pixel above/below it, the one left/right of
-        // it; in the four corner tiles the inner pixel (no other duty) takes the corner
-        const bool top = tc.ty == 0, bot = tc.ty == 6, lef = tc.tx == 0, rig = tc.tx == 6;
-        const bool rrow = live && ((top && pa == 0) || (bot && pa == 1));
-        const bool rcol = live && ((lef && pb == 0) || (rig && pb == 1));
-        const bool rcor = live && (top || bot) && (lef || rig) && pa == (top ? 1 : 0) && pb == (lef ? 1 : 0);
-        const int ry = top ? 0 : WINO_HW - 1, rx = lef ? 0 : WINO_HW - 1;
-        if (rrow || rcor)
-          buf_store16(zero4, rsrc_out, (unsigned)((img + ry * WINO_HW + (rcor ? rx : pxx)) * K * sizeof(float)) + kbyte, 0);
-        if (rcol)
-          buf_store16(zero4, rsrc_out, (unsigned)((img + py * WINO_HW + rx) * K * sizeof(float)) + kbyte, 0);
       }
     }
     phase(3);
@@ -743,6 +772,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
     }
   }
 #undef A_OFF
+#undef PIN2
 
   // diagnostic builds: stamps go past the N images of `out` (the tool allocates that room)
   if (ABLATE & 2048) {

@@ -19,7 +19,7 @@ static int g_grid = 256;   // logical workgroups (argv[2]); 0 = one whole item p
 static int grid_for(int N, int K) {
   const int nTB = (N * 49 + TB - 1) / TB;
   if (g_grid) return g_grid;
-  return (nTB * (K / KB) + 7) & ~7;   // item-per-workgroup when the item count is a multiple of 8
+  return nTB * (K / KB);   // one whole item per workgroup
 }
 
 template <int AB>
@@ -47,7 +47,7 @@ float run(const float* in, const float* U, const float* b, const float* s, float
 
 int main(int argc, char** argv) {
   const int C = argc > 1 ? atoi(argv[1]) : 256, K = C;
-  if (argc > 2) g_grid = atoi(argv[2]) & ~7;
+  if (argc > 2) g_grid = atoi(argv[2]);
   CK(hipMalloc(&g_slabs, (size_t)2 * 4096 * SLAB_BYTES));
   CK(hipMalloc(&g_tickets, 65536 * 4));
   std::vector<int> Ns = {1, 83, 128};
