@@ -40,26 +40,10 @@ constexpr int LDS_BYTES = N_RSTAGE * RAW_BYTES + N_USTAGE * U_BYTES;  // 163840 
 constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
 constexpr int PF = 2;                        // filter-fragment prefetch distance (points)
 constexpr int SLAB_BYTES = TB * 4 * KB * 4;  // 65536: pre-BN output of one item (64 tiles x 2x2 px x 64 k)
-constexpr int FLAG_OFF = LDS_BYTES - 16;     // LDS word that broadcasts the ticket (outside the epilogue image)
 #ifndef WINO_DMA0
-#define WINO_DMA0 4   // tuned with tools/ablate_fused: 0/2/4/6/8 -> 39.4/38.8/38.6/38.7/40.5 cycles per MFMA
+#define WINO_DMA0 4   // tuned with tools/ablate_fused: 0..4 equal, 6 +1 %, 8 +4 %
 #endif
 constexpr int DMA0 = WINO_DMA0;              // first point-step that issues an LDS-DMA piece
-#ifndef WINO_PRIO
-#define WINO_PRIO 0
-#endif
-#ifndef WINO_XF_PACKED
-#define WINO_XF_PACKED 1
-#endif
-#ifndef WINO_PIN
-#define WINO_PIN 0
-#endif
-#ifndef WINO_MFMA_ASM
-#define WINO_MFMA_ASM 1
-#endif
-#ifndef WINO_DMA_MODE
-#define WINO_DMA_MODE 0   // 0: one piece per step, all waves in the same steps; 1: two pieces per step, SIMD mates in alternate steps
-#endif
 
 // s_waitcnt lgkmcnt(n) alone (vmcnt/expcnt fields at "no wait"); n folds to a literal once the
 // point loop is unrolled.
@@ -234,32 +218,12 @@ wino_f2_fused_kernel(const FusedParams prm) {
   }
   asm volatile("" : "+v"(b_base[1]));
 
-  // B^T d B pieces (d, tmp, v are [row i][col j] = index 4i + j; Winograd point e = 4i + j).
-  // Written per component: with WINO_SCALAR_XFORM the build passes -fno-slp-vectorize so that
-  // these stay v_add_f32/v_sub_f32 instead of v_pk_add_f32 (packed f32 VALU next to MFMAs
-  // measured slower than two plain ops on this chip).
-#if WINO_XF_PACKED
-  typedef f32x2 P2;   // two channels as a register pair: v_pk_add_f32
+  // B^T d B pieces (d, tmp, v are [row i][col j] = index 4i + j; Winograd point e = 4i + j), on
+  // channel pairs (v_pk_add_f32)
+  typedef f32x2 P2;
   auto sub2 = [](const P2& a, const P2& b) { return a - b; };
   auto add2 = [](const P2& a, const P2& b) { return a + b; };
   auto ld2 = [](const char* p) { return *(const f32x2*)p; };
-#define PIN2(val) asm volatile("" : "+v"(val))
-#else
-  struct P2 { float x, y; };  // two channels, deliberately NOT a vector type
-  auto sub2 = [](const P2& a, const P2& b) { P2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; };
-  auto add2 = [](const P2& a, const P2& b) { P2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; };
-  auto ld2 = [](const char* p) {
-    const f32x2 t = *(const f32x2*)p;
-    P2 r;
-    r.x = t.x;
-    r.y = t.y;
-#ifdef WINO_SCALAR_XFORM
-    asm volatile("" : "+v"(r.x), "+v"(r.y));  // opaque scalars: no <2 x float> re-vectorisation
-#endif
-    return r;
-  };
-#define PIN2(val) asm volatile("" : "+v"((val).x), "+v"((val).y))
-#endif
   auto tmp_col = [&](P2* tmp, const P2* d, int j) {  // B^T d, column j
     tmp[0 * 4 + j] = sub2(d[0 * 4 + j], d[2 * 4 + j]);
     tmp[1 * 4 + j] = add2(d[1 * 4 + j], d[2 * 4 + j]);
@@ -381,9 +345,10 @@ wino_f2_fused_kernel(const FusedParams prm) {
     dma_advance();
   }
   {
-    P2 d[16], tmp[16];
+    P2 d[16];
 #pragma unroll
     for (int px = 0; px < 16; px++) d[px] = ld2(smem + A_OFF(px));
+    P2 tmp[16];
 #pragma unroll
     for (int j = 0; j < 4; j++) tmp_col(tmp, d, j);
 #pragma unroll
@@ -420,8 +385,6 @@ wino_f2_fused_kernel(const FusedParams prm) {
     // spread out the SIMD's other wave covers that with its MFMAs; starting at step 4 leaves the
     // last pieces a third of an iteration of flight time before the next vmcnt(0).
     const bool dma_on = it + 2 < L;
-    const bool dma_m0 = dma_on && w < 4, dma_m1 = dma_on && w >= 4;
-    (void)dma_m0; (void)dma_m1;
     const char* rst = smem;   // raw_{it+1}: the stage is in a_lo[]
     const char* ucur0 = smem + b_base[0] + us_cur * U_BYTES;   // U_it
     const char* ucur1 = smem + b_base[1] + us_cur * U_BYTES;
@@ -435,17 +398,6 @@ wino_f2_fused_kernel(const FusedParams prm) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-#if WINO_PRIO == 1     // the younger wave of each SIMD (w >= 4) always ahead of the older one
-      if (e == 0) { if (w >= 4) __builtin_amdgcn_s_setprio(1); }
-#elif WINO_PRIO == 2   // mates lead half an iteration each
-      if (e == 0) { if (w >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-      if (e == 8) { if (w >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-#elif WINO_PRIO == 3   // mates lead alternate steps
-      if ((e & 1) == 0) { if (w >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-      else { if (w >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-#elif WINO_PRIO == 4   // mates lead alternate quarters
-      if ((e & 3) == 0) { if ((w >= 4) == (((e >> 2) & 1) == 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#endif
       // -- top of the step: every LDS request of this step, before any MFMA.  Consumers sit
       //    at least one step later, so their waits are counted (lgkmcnt(N)), not drains.
       if (ABLATE & 64) {
@@ -459,27 +411,20 @@ wino_f2_fused_kernel(const FusedParams prm) {
         bfn[e + PF - 16][0] = *(const f32x2*)(unxt0 + (e + PF - 16) * 2048);
         bfn[e + PF - 16][1] = *(const f32x2*)(unxt1 + (e + PF - 16) * 2048);
       }
-#if WINO_DMA_MODE == 0
       if (e >= DMA0 && e < DMA0 + 4) {
         if (dma_on) issue_raw1(rs_dma, e - DMA0);
       } else if (e >= DMA0 + 4 && e < DMA0 + 8) {
         if (dma_on) issue_u1(us_dma, e - DMA0 - 4);
       }
-#else
-      // waves w and w+4 share a SIMD: they take alternate steps, two pieces each, so that a wave
-      // held up in the VMEM queue always has a mate with nothing but MFMAs to issue
-      if (e >= DMA0 && e < DMA0 + 8) {
-        const int kk = (e - DMA0) >> 1;   // 0,1: raw pairs; 2,3: filter pairs
-        if (((e - DMA0) & 1) == 0 ? dma_m0 : dma_m1) {
-          if (kk < 2) { issue_raw1(rs_dma, 2 * kk); issue_raw1(rs_dma, 2 * kk + 1); }
-          else { issue_u1(us_dma, 2 * (kk - 2)); issue_u1(us_dma, 2 * (kk - 2) + 1); }
-        }
-      }
-#endif
-      // next iteration's A operand rides along: steps 0-7 read the patch (two pixels of patch
-      // column e>>1 per step), steps 2,4,6,8 form B^T d column by column, steps 9-15 form
-      // (B^T d) B in place over the points that have retired.  (After the last iteration this
-      // works on stale LDS; the result is never used -- cheaper than a branch per step.)
+      // next iteration's A operand rides along: steps 0-7 read its patch (two pixels of patch
+      // column e>>1 per step); B^T d B itself is written below, after the step's MFMAs, and is
+      // deliberately NOT pinned to its step: the optimizer sinks it behind the last MFMA of the
+      // iteration, where it runs as one burst of packed adds while the SIMD's other wave still
+      // has MFMAs to issue.  Measured alternatives, all slower: pinned to steps 2-15 (scalar or
+      // packed, +3..+8 %: arithmetic between a wave's MFMAs delays its own next MFMA, and when it
+      // waits on a patch read the whole wave stalls behind it, in-order issue); B^T d as the
+      // loop-carried state with every point formed one step ahead of its use (+8 %).  (After the
+      // last iteration this works on stale LDS; the result is never used -- cheaper than a branch.)
       if (e < 8 && !(ABLATE & 32)) {
         const int j = e >> 1, i0 = (e & 1) * 2;
         d[(i0 + 0) * 4 + j] = ld2(rst + A_OFF((i0 + 0) * 4 + j));
@@ -488,20 +433,12 @@ wino_f2_fused_kernel(const FusedParams prm) {
       __builtin_amdgcn_sched_barrier(0);
       if (!(ABLATE & 96)) wait_lds(lds_wait_count(e));
       __builtin_amdgcn_sched_barrier(0);
-      // (the empty asm statements pin the transform arithmetic to its step: without them the
-      //  optimizer sinks it out of the MFMA shadow towards the next iteration's first use)
-      if (e >= 2 && e <= 8 && (e & 1) == 0 && !(ABLATE & 32)) {
-        const int j = (e >> 1) - 1;
-        tmp_col(tmp, d, j);
-#pragma unroll
-        for (int i = 0; i < 4; i++) if (WINO_PIN & 1) PIN2(tmp[i * 4 + j]);
-      }
+      if (e >= 2 && e <= 8 && (e & 1) == 0 && !(ABLATE & 32)) tmp_col(tmp, d, (e >> 1) - 1);
       const P2 a = v[e];
       const f32x2 b0 = bf[e][0], b1 = bf[e][1];
       if (ABLATE & 4) {  // keep the operands live, skip the matrix pipe
         asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y));
       } else {
-#if WINO_MFMA_ASM
         // Tied destination: the accumulate chain stays in place (same vDst as SrcC is the
         // back-to-back form the matrix pipe forwards without wait states).  Left to the register
         // allocator, the builtin form ping-pongs every accumulator through a temporary tuple
@@ -512,27 +449,17 @@ wino_f2_fused_kernel(const FusedParams prm) {
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][1]) : "v"(a.x), "v"(b1.x));
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][0]) : "v"(a.y), "v"(b0.y));
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][1]) : "v"(a.y), "v"(b1.y));
-#else
-        acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc[e][0], 0, 0, 0);
-        acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc[e][1], 0, 0, 0);
-        acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc[e][0], 0, 0, 0);
-        acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc[e][1], 0, 0, 0);
-#endif
       }
       if (!(ABLATE & 32)) {
-        auto v_pinned = [&](int pt) {
-          v_point(v, tmp, pt);
-          if (WINO_PIN & 2) PIN2(v[pt]);
-        };
         if (e >= 9 && e < 15) {  // points 2(e-9), 2(e-9)+1 < e have retired
-          v_pinned(2 * (e - 9));
-          v_pinned(2 * (e - 9) + 1);
+          v_point(v, tmp, 2 * (e - 9));
+          v_point(v, tmp, 2 * (e - 9) + 1);
         }
         if (e == 15) {
-          v_pinned(12);
-          v_pinned(13);
-          v_pinned(14);
-          v_pinned(15);
+          v_point(v, tmp, 12);
+          v_point(v, tmp, 13);
+          v_point(v, tmp, 14);
+          v_point(v, tmp, 15);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -772,7 +699,6 @@ wino_f2_fused_kernel(const FusedParams prm) {
     }
   }
 #undef A_OFF
-#undef PIN2
 
   // diagnostic builds: stamps go past the N images of `out` (the tool allocates that room)
   if (ABLATE & 2048) {
