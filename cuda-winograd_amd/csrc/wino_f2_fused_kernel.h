@@ -423,8 +423,11 @@ wino_f2_fused_kernel(const FusedParams prm) {
       // has MFMAs to issue.  Measured alternatives, all slower: pinned to steps 2-15 (scalar or
       // packed, +3..+8 %: arithmetic between a wave's MFMAs delays its own next MFMA, and when it
       // waits on a patch read the whole wave stalls behind it, in-order issue); B^T d as the
-      // loop-carried state with every point formed one step ahead of its use (+8 %).  (After the
-      // last iteration this works on stale LDS; the result is never used -- cheaper than a branch.)
+      // loop-carried state with every point formed one step ahead of its use (+8 %); the two waves
+      // of a SIMD phase-shifted, waves 4-7 transforming at the top of the next iteration instead
+      // (+6 %: the older wave then runs even further ahead and waits longer at the barrier).
+      // (After the last iteration this works on stale LDS; the result is never used -- cheaper
+      // than a branch.)
       if (e < 8 && !(ABLATE & 32)) {
         const int j = e >> 1, i0 = (e & 1) * 2;
         d[(i0 + 0) * 4 + j] = ld2(rst + A_OFF((i0 + 0) * 4 + j));
