@@ -226,26 +226,25 @@ static int sk_workspace(int dev, hipStream_t s, int G, size_t items, float** sla
   return WINO_OK;
 }
 
-// Launch geometry of the throughput kernel: G logical workgroups share T = items * C/8 chunk
-// iterations evenly (stream-K).  Two candidates are priced with a small cost model, in units of one
-// chunk iteration (~2.2 us at 2.3 GHz):
-//   * G = items: every workgroup owns whole items, no hand-off; with more items than CUs the
-//     hardware runs ceil(items / CUs) rounds;
-//   * G = CUs (capped so that a workgroup keeps >= SK_MIN_ITERS iterations): one round, every CU
-//     gets T/G iterations, but a range cuts items -> about one more epilogue per workgroup and
-//     the slab hand-off.
-// Measured on MI355X (N = 128): 256 channels 392 items -> stream-K 136 us vs 156 us; 128 channels
-// 196 items -> whole items 44 us vs 54 us.  An epilogue costs ~2.3 iterations, the hand-off
-// (drain, ticket, gather of the range's last segment) ~4.8.
+// Launch geometry of the throughput kernel (see the header of wino_f2_fused_kernel.h): G logical
+// workgroups run items / G whole-item rounds and share the remaining items % G items as a
+// stream-K tail.  Two candidates are priced with a small cost model, in units of one chunk
+// iteration (~2.2 us at 2.3 GHz):
+//   * G = items when that fits the CUs: whole items only, no tail, no hand-off;
+//   * G = CUs (capped so that a workgroup keeps >= SK_MIN_ITERS iterations).
+// Measured on MI355X (N = 128): 256 channels 392 items -> G = 256 (1 round + 17-iteration tail)
+// 125 us vs 151 us for two whole-item rounds; 128 channels 196 items -> G = 196, 43 us vs 51 us
+// for G = 256 (all tail).  An epilogue costs ~2.3 iterations, the tail's hand-off ~4.8.
 constexpr int SK_MIN_ITERS = 8;
 constexpr double SK_EPILOGUE_ITERS = 2.3, SK_HANDOFF_ITERS = 4.8;
-static double sk_cost(long long items, int nchunks, int cus, long long G) {
-  const long long T = items * nchunks;
-  const long long per = (T + G - 1) / G;
-  const long long rounds = (G + cus - 1) / cus;
-  const bool aligned = items % G == 0;   // every range is a whole number of items
-  const double nseg = (double)((per + nchunks - 1) / nchunks) + (aligned ? 0.0 : 1.0);
-  return (double)rounds * ((double)per + nseg * SK_EPILOGUE_ITERS + (aligned ? 0.0 : SK_HANDOFF_ITERS));
+static double sk_cost(long long items, int nchunks, long long G) {
+  const long long ndp = items / G, tail_items = items % G;
+  double c = (double)ndp * (nchunks + SK_EPILOGUE_ITERS);
+  if (tail_items) {
+    const long long per = (tail_items * nchunks + G - 1) / G;
+    c += (double)per + ((double)((per + nchunks - 1) / nchunks) + 1.0) * SK_EPILOGUE_ITERS + SK_HANDOFF_ITERS;
+  }
+  return c;
 }
 static int sk_grid(int dev, long long items, int nchunks, int* G) {
   int cus = 0;
@@ -254,11 +253,10 @@ static int sk_grid(int dev, long long items, int nchunks, int* G) {
   const char* m_env = getenv("WINO_SK_MIN_ITERS");   // tests can sweep the decomposition
   const int min_iters = m_env && atoi(m_env) > 0 ? atoi(m_env) : SK_MIN_ITERS;
   const long long T = items * nchunks;
-  long long g_sk = cus;
-  if (g_sk > T / min_iters) g_sk = T / min_iters;
-  if (g_sk < 1) g_sk = 1;
-  long long g = g_sk;
-  if (items <= 65535 && sk_cost(items, nchunks, cus, items) <= sk_cost(items, nchunks, cus, g_sk)) g = items;
+  long long g = cus;
+  if (g > T / min_iters) g = T / min_iters;
+  if (g < 1) g = 1;
+  if (items <= cus && sk_cost(items, nchunks, items) <= sk_cost(items, nchunks, g)) g = items;
   if (g_env && atoi(g_env) >= 1) g = atoi(g_env);
   if (g > 65535) g = 65535;
   *G = (int)g;
@@ -335,8 +333,8 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
   float* slabs = nullptr;
   unsigned* tickets = nullptr;
   if (int rc = sk_workspace(dev, (hipStream_t)s, G, items, &slabs, &tickets)) return rc;
-  const long long T = (long long)items * (C / BC);
-  const FusedParams prm = {in, U, N, C, K, relu, nTB, (unsigned)(T / G), (unsigned)(T % G),
+  const long long Tt = (long long)(items % (size_t)G) * (C / BC);   // the stream-K tail's iterations
+  const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
                            bnBias, bnScale, out, slabs, tickets};
   hipLaunchKernelGGL((wino_f2_fused_kernel<0>), dim3(G), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s, prm);
   return launch_status("wino_f2_fused_kernel");

@@ -8,19 +8,28 @@
 //   32 skip the A-path reads+transform 64 skip the B-fragment reads  512 skip the output stores
 //   1024 skip the stream-K slab hand-off (partial segments are dropped)
 //
-// Work decomposition (stream-K): the launch's work is the linear sequence of "chunk iterations"
+// Work decomposition: the launch's work is a set of "chunk iterations"
 //   (item, chunk),  item = (tile block, k block),  chunk = 8 input channels,
-// T = nTB * K/64 * C/8 of them, all of equal cost.  Logical workgroup l of G takes the contiguous
-// range [l*T/G, (l+1)*T/G): at 256 channels and N = 128, T = 392 * 32 = 12544 = 256 * 49, i.e. every
-// CU gets exactly 49 iterations instead of the 1 or 2 whole items (32 or 64 iterations) of an
-// item-per-workgroup grid.  A range cuts an item into at most two partial SEGMENTS per workgroup
-// (the head of its range, the tail of its range).  A partial segment applies A^T m A to its partial
-// sums (the inverse transform is linear), publishes the 64 KB pre-BN result as a write-through slab
-// and draws a ticket on the item's counter; the workgroup that draws the last ticket adds the other
-// segments' slabs (in segment order, whoever is last: the result is bitwise reproducible), applies
-// BN + ReLU and stores.  Nobody ever waits on another workgroup, so there is no residency
-// assumption and no deadlock; the hand-off follows the write-through recipe (sc1 stores, every
-// storing wave drains vmcnt, barrier, one relaxed agent-scope ticket add, sc1 loads by the reducer).
+// nTB * K/64 * C/8 of them, all of equal cost.  G logical workgroups (at most one per CU) share
+// them in two phases:
+//   * whole-item rounds: ndp = items / G rounds in which workgroup l owns item r*G + l outright.
+//     All workgroups then walk the same chunk index at the same time, so the K/64 k-blocks that
+//     share a tile block's patches and the tile blocks that share a filter chunk hit each other's
+//     lines in the XCD's L2 (88 % hit rate);
+//   * a stream-K tail for the remaining items % G items: their chunk iterations, in item-major
+//     order, are cut into G equal contiguous ranges.  At 256 channels and N = 128: 392 items on
+//     256 CUs = one whole item (32 iterations) + 17 tail iterations each = 49 per CU, instead of
+//     the 64 a second whole-item round would cost.  (All 392 items as one stream-K range were
+//     measured too: the scattered channel phases halve the L2 hit rate and quadruple HBM traffic.)
+// A tail range cuts an item into at most two partial SEGMENTS per workgroup (the head and the tail
+// of its range).  A partial segment applies A^T m A to its partial sums (the inverse transform is
+// linear), publishes the 64 KB pre-BN result as a write-through slab and draws a ticket on the
+// item's counter; the wave that draws the last ticket adds the other segments' slabs (in segment
+// order, whoever is last: the result is bitwise reproducible), applies BN + ReLU and stores.
+// Nobody ever waits on another workgroup, so there is no residency assumption and no deadlock; the
+// hand-off follows the write-through recipe (sc1 stores, the storing wave drains vmcnt, one relaxed
+// agent-scope ticket add, sc1 loads by the reducer).  The tail runs FIRST: its hand-offs then
+// complete in the middle of the launch and every workgroup ends with a whole item.
 #pragma once
 #include "wino_common.h"
 
@@ -124,7 +133,8 @@ struct FusedParams {
   const float* in;
   const float* Uq;
   int N, C, K, relu, nTB;
-  unsigned sk_q, sk_rem;       // T = nTB * K/64 * C/8 = sk_q * gridDim.x + sk_rem
+  int ndp;                     // whole-item rounds: items / gridDim.x
+  unsigned sk_q, sk_rem;       // tail: (items % gridDim.x) * C/8 = sk_q * gridDim.x + sk_rem iterations
   // ---- epilogue only ----
   const float* bnBias;
   const float* bnScale;
@@ -141,6 +151,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
   const float* __restrict__ Uq = prm.Uq;
   const int N = prm.N, C = prm.C, K = prm.K, relu = prm.relu, nTB = prm.nTB;
   const unsigned sk_q = prm.sk_q, sk_rem = prm.sk_rem;
+  const int ndp = prm.ndp;
 
   // XCD-aware block -> logical workgroup: blocks b and b+8 share an XCD (its L2), so consecutive
   // logical workgroups -- which walk consecutive items, i.e. the K/64 k-blocks that read the same
@@ -151,9 +162,11 @@ wino_f2_fused_kernel(const FusedParams prm) {
   const int G = gridDim.x;
   const int lg = (int)(blockIdx.x & 7) * (G >> 3) + ((int)(blockIdx.x & 7) < (G & 7) ? (int)(blockIdx.x & 7) : (G & 7)) +
                  (int)(blockIdx.x >> 3);
-  // T = nTB * KBLK * nchunks = sk_q * G + sk_rem chunk iterations in all
-  const unsigned i_begin = sk_start(lg, sk_q, sk_rem, G);
-  const int L = (int)(sk_start(lg + 1, sk_q, sk_rem, G) - i_begin);   // chunk iterations of this workgroup
+  // tail: items ndp*G .. , (sk_q * G + sk_rem) chunk iterations in item-major order; then the rounds
+  const int tail_item0 = ndp * G;
+  const unsigned t_begin = __builtin_amdgcn_readfirstlane(sk_start(lg, sk_q, sk_rem, G));
+  const int Lt = (int)(__builtin_amdgcn_readfirstlane(sk_start(lg + 1, sk_q, sk_rem, G)) - t_begin);   // tail iterations of this workgroup
+  const int L = Lt + ndp * nchunks;                                     // all its chunk iterations
 
   // ---- ring pass: the output's zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:
   // 163,243) is written here, once per launch, as a flat list of 16-byte units -- N images x 60
@@ -249,6 +262,16 @@ wino_f2_fused_kernel(const FusedParams prm) {
     return t;
   };
 
+  // Opaque pointer to the kernel's own arguments (constant address space: scalar loads).  The rare
+  // paths below (tile-block switch of the DMA stream, epilogue) re-read what they need through it
+  // instead of keeping those scalars alive across the main loop, which is out of SGPRs.
+  typedef const __attribute__((address_space(4))) FusedParams* KernargPtr;
+  auto kernarg = []() {
+    KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+  };
+
   // ---- the DMA stream: walks (item, chunk) linearly, two iterations ahead of the MFMAs ------
   // raw stage layout: [tile 0..63][unit' 0..31] of 16 B; unit' = px'*2 + half'.
   // LDS unit (t, px', half') holds pixel px = px' ^ (t&7), channel half = half' ^ bit3(t).
@@ -258,12 +281,14 @@ wino_f2_fused_kernel(const FusedParams prm) {
   unsigned raw_off[4];        // per-lane source offsets of the DMA stream's tile block
   unsigned d_soff_raw = 0;    // + chunk * 32 B
   unsigned d_soff_u = 0;      // filter chunk of (k block, chunk), this wave's 1-KiB column
-  int d_item, d_chunk, d_tb = -1;
+  int d_item, d_chunk, d_tail, d_tb = -1;   // d_tail: tail iterations the stream still has to issue
   auto dma_set_item = [&](int item) {   // wave-uniform; the per-lane part only when the tile block changes
     const int tb = item / KBLK, kb = item - tb * KBLK;
     d_item = item;
     if (tb != d_tb) {
       d_tb = tb;
+      KernargPtr kp = kernarg();
+      const int C = kp->C, totalTiles = kp->N * WINO_TILES;
       const int up = lane & 31;
       const int pxp = up >> 1, halfp = up & 1;
 #pragma unroll
@@ -278,17 +303,32 @@ wino_f2_fused_kernel(const FusedParams prm) {
         raw_off[j] = (unsigned)((((size_t)(tc.n * WINO_HW + y) * WINO_HW + x) * C + half * 4) * sizeof(float));
       }
     }
-    d_soff_raw = (unsigned)(d_chunk * (BC * sizeof(float)));
-    d_soff_u = (unsigned)((kb * U_CHUNK_FLOATS + w * 256) * sizeof(float)) + d_chunk * u_chunk_stride;
+    d_soff_raw = __builtin_amdgcn_readfirstlane((unsigned)(d_chunk * (BC * sizeof(float))));
+    d_soff_u = __builtin_amdgcn_readfirstlane((unsigned)((kb * U_CHUNK_FLOATS + w * 256) * sizeof(float)) + d_chunk * u_chunk_stride);
+    // ("+s": pins the loop-carried scalars to SGPRs.  Short of SGPRs, the compiler otherwise keeps
+    //  one of them in a VGPR and wraps every LDS-DMA that uses it in a waterfall loop.)
+    asm volatile("" : "+s"(d_soff_raw), "+s"(d_soff_u));
+  };
+  auto pin_dma_state = [&]() {   // "+s": keep the loop-carried scalars in SGPRs (see dma_set_item)
+    d_item = __builtin_amdgcn_readfirstlane(d_item);
+    d_chunk = __builtin_amdgcn_readfirstlane(d_chunk);
+    d_tail = __builtin_amdgcn_readfirstlane(d_tail);
+    d_tb = __builtin_amdgcn_readfirstlane(d_tb);
+    asm volatile("" : "+s"(d_item), "+s"(d_chunk), "+s"(d_tail), "+s"(d_tb));
   };
   auto dma_advance = [&]() {
-    if (++d_chunk == nchunks) {
+    if (d_tail > 0 && --d_tail == 0) {          // the tail range is issued: on to the whole items
       d_chunk = 0;
-      dma_set_item(d_item + 1);
+      dma_set_item(lg);
+    } else if (++d_chunk == nchunks) {
+      d_chunk = 0;
+      dma_set_item(d_tail > 0 ? d_item + 1 : d_item + G);
     } else {
-      d_soff_raw += BC * sizeof(float);
+      d_soff_raw += (unsigned)(BC * sizeof(float));
       d_soff_u += u_chunk_stride;
+      asm volatile("" : "+s"(d_soff_raw), "+s"(d_soff_u));
     }
+    pin_dma_state();
   };
   // LDS map: [R0 32K][R1 32K][U0 32K][U1 32K][U2 32K]; R = raw 4x4 patches, U = filter chunk.
   // Both DMA streams run TWO iterations ahead of the MFMAs, across item boundaries:
@@ -310,8 +350,11 @@ wino_f2_fused_kernel(const FusedParams prm) {
   };
 
   // ---- the compute stream's position --------------------------------------------
-  int c_item = (int)(i_begin / (unsigned)nchunks);
-  int c_chunk = (int)(i_begin - (unsigned)c_item * (unsigned)nchunks);
+  // (readfirstlane: the divisions run on the vector unit; without it the walkers' scalar state --
+  //  and with it the LDS-DMA scalar offsets -- would be treated as divergent)
+  int c_tail = Lt;                 // tail iterations still to compute
+  int c_item = __builtin_amdgcn_readfirstlane(Lt > 0 ? tail_item0 + (int)(t_begin / (unsigned)nchunks) : lg);
+  int c_chunk = __builtin_amdgcn_readfirstlane(Lt > 0 ? (int)(t_begin % (unsigned)nchunks) : 0);
   int seg_c0 = c_chunk;            // first chunk of the current segment
   int pend_item = -1;              // a head segment whose ticket is still to be drawn
 
@@ -326,6 +369,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
 
   // ---- prologue: iterations 0 and 1 in flight; V_0 and the first fragments un-pipelined -----
   d_chunk = c_chunk;
+  d_tail = Lt;
   dma_set_item(c_item);
 #pragma unroll
   for (int j = 0; j < 4; j++) issue_raw1(0, j);
@@ -502,10 +546,10 @@ wino_f2_fused_kernel(const FusedParams prm) {
     asm volatile("" : "+s"(wv));
     const int e_t16 = ln & 15, e_h = ln >> 4, e_wt = wv >> 1, e_wk = wv & 1;
     char* wreg = smem + (wv < 4 ? rfree + wv * 8192 : ufree + (wv - 4) * 8192);
-    // (constant address space: scalar loads, so the descriptors stay in SGPRs)
-    typedef const __attribute__((address_space(4))) FusedParams* KernargPtr;
-    KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
+    KernargPtr kp = kernarg();
+    const int N = kp->N, K = kp->K, relu = kp->relu, KBLK = K >> 6, totalTiles = N * WINO_TILES;
+    const unsigned sk_q = kp->sk_q, sk_rem = kp->sk_rem;
+    const int tail_item0 = kp->ndp * G;
     const float* bnBias = kp->bnBias;
     const float* bnScale = kp->bnScale;
     unsigned* tickets = kp->tickets;
@@ -594,7 +638,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
       if (!(j == 0 && whole)) {
         // which logical workgroups share `item`: walk outwards from lg.  With more workgroups
         // than iterations some own nothing; they are not segments.
-        const unsigned x0 = (unsigned)item * (unsigned)nchunks, x1 = x0 + nchunks - 1;
+        const unsigned x0 = (unsigned)(item - tail_item0) * (unsigned)nchunks, x1 = x0 + nchunks - 1;   // tail space
         int gA = lg, gB = lg;
         while (sk_start(gA, sk_q, sk_rem, G) > x0) gA--;
         while (gB + 1 < G && sk_start(gB + 1, sk_q, sk_rem, G) <= x1) gB++;
@@ -677,8 +721,9 @@ wino_f2_fused_kernel(const FusedParams prm) {
     int it = 0;
 #pragma unroll 1
     for (;;) {
-      const int n = nchunks - c_chunk < L - it ? nchunks - c_chunk : L - it;   // iterations of this segment
-      c_chunk += n - 1;                                                         // its last chunk
+      // iterations of this segment: to the end of the item, or of the tail range
+      const int n = c_tail > 0 && c_tail < nchunks - c_chunk ? c_tail : nchunks - c_chunk;
+      c_chunk += n - 1;   // its last chunk
       int us_last = us;
 #pragma unroll 1
       for (int k = 0; k < n; k++) {
@@ -696,7 +741,8 @@ wino_f2_fused_kernel(const FusedParams prm) {
       epilogue(last_of_range, (it & 1) * RAW_BYTES, N_RSTAGE * RAW_BYTES + us_last * U_BYTES);
       if (ABLATE & 2048) { const unsigned long long t = stamp(); st_epi += t - st_prev; st_prev = t; }
       if (last_of_range) break;
-      c_item++;
+      if (c_tail > 0 && (c_tail -= n) == 0) c_item = lg;   // tail done: first whole item
+      else c_item += c_tail > 0 ? 1 : G;
       c_chunk = 0;
       seg_c0 = 0;
     }
