@@ -92,6 +92,22 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   const int xcd = bid & 7, slot = bid >> 3;
   const int nb = slot % NBLK;
   const int mb = (slot / NBLK) * 8 + xcd;
+  if (c_padded && !(ABLATE & 512)) {
+    // ring pass: the padded output's zero ring (the 3x3 layer's padding) as a flat list of
+    // 16-byte units -- M/196 images x 60 ring pixels x Kout/4 units -- split over the grid
+    const unsigned upp = (unsigned)Kout >> 2;
+    const unsigned long long U = (unsigned long long)(M / (WINO_PQ * WINO_PQ)) * 60u * upp;
+    const unsigned u_begin = (unsigned)(U * bid / gridDim.x), u_end = (unsigned)(U * (bid + 1ull) / gridDim.x);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned u = u_begin + threadIdx.x; u < u_end; u += 64 * NW) {
+      const unsigned pid = u / upp, unit = u - pid * upp;
+      const unsigned n = pid / 60u, q = pid - n * 60u;
+      // q: 0..15 row 0, 16..31 row 15, 32..45 column 0 (rows 1..14), 46..59 column 15
+      const unsigned y = q < 16 ? 0u : q < 32 ? (unsigned)(WINO_HW - 1) : q < 46 ? q - 31u : q - 45u;
+      const unsigned x = q < 16 ? q : q < 32 ? q - 16u : q < 46 ? 0u : (unsigned)(WINO_HW - 1);
+      *(f32x4*)(Cout + ((size_t)(n * WINO_HW + y) * WINO_HW + x) * Kout + unit * 4) = zero4;
+    }
+  }
   if (mb >= nMB) return;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -198,36 +214,54 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     if (it + 1 < nk) body(std::integral_constant<int, 1>{}, it + 1);
   }
 
-  // ---- epilogue: BN (+residual) (+ReLU), C/D layout col = lane&15, row = 4*(lane>>4)+i ----
-  const int col = n0 + 16 * w + r16;
-  const float sc = bnScale[col], bi = bnBias[col];
+  // ---- epilogue: BN (+residual) (+ReLU).  C/D layout: col = lane&15, row = 4*(lane>>4)+i.
+  // The 112 x BN tile goes through LDS (the pipeline stages are free now) so that it leaves as
+  // whole rows -- 16 B per lane, 512 / 256 contiguous bytes per output row -- instead of 64-byte
+  // fragments written 4 bytes per lane; the residual is read the same way.
+  // Image [row][col] floats; the 16-float column group is XORed with (row>>2)&3 = the MFMA row
+  // group h, which keeps the ds_write_b32 of the four row groups on disjoint banks.
+  __syncthreads();   // every wave is done with the pipeline stages; no LDS-DMA is in flight
+  float* img = (float*)smem;
+  {
+    const int col = n0 + 16 * w + r16;
+    const float sc = bnScale[col], bi = bnBias[col];
+    float* wr = img + (4 * h) * BN + ((16 * w + r16) ^ (h << 4));
 #pragma unroll
-  for (int rb = 0; rb < RB; rb++) {
+    for (int rb = 0; rb < RB; rb++) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const long row = m0 + rb * 16 + 4 * h + i;
-      if (row < M) {
+      for (int i = 0; i < 4; i++) {
         float y = sc * acc[rb][i] + bi;
-        if (add_res) y += R[row * Kout + col];
-        if (relu) y = fmaxf(y, 0.f);
-        if (ABLATE & 512) {
-          asm volatile("" ::"v"(y));
-        } else if (!c_padded) {
-          Cout[row * Kout + col] = y;
-        } else {
-          // row = pixel (n, py-1, px-1) of the 14x14 map -> interior of [N][16][16][Kout];
-          // edge pixels also clear the ring pixels next to them (the 3x3 layer's padding)
-          const long n = row / (WINO_PQ * WINO_PQ);
-          const int rem = (int)(row - n * (WINO_PQ * WINO_PQ));
-          const int py = rem / WINO_PQ + 1, px = rem % WINO_PQ + 1;
-          float* img = Cout + (size_t)n * WINO_HW * WINO_HW * Kout + col;
-          img[(size_t)(py * WINO_HW + px) * Kout] = y;
-          const int ry = py == 1 ? 0 : (py == WINO_PQ ? WINO_HW - 1 : -1);
-          const int rx = px == 1 ? 0 : (px == WINO_PQ ? WINO_HW - 1 : -1);
-          if (ry >= 0) img[(size_t)(ry * WINO_HW + px) * Kout] = 0.f;
-          if (rx >= 0) img[(size_t)(py * WINO_HW + rx) * Kout] = 0.f;
-          if (ry >= 0 && rx >= 0) img[(size_t)(ry * WINO_HW + rx) * Kout] = 0.f;
+        if (relu && !add_res) y = fmaxf(y, 0.f);
+        wr[(rb * 16 + i) * BN] = y;
+      }
+    }
+  }
+  __syncthreads();
+  if (ABLATE & 512) return;
+  {
+    constexpr int LPR = BN / 4;          // lanes per output row
+    constexpr int RPI = 64 / LPR;        // rows per store instruction
+    constexpr int RPW = BM / NW;         // rows per wave
+    static_assert(RPW % RPI == 0, "rows per wave must be a whole number of store instructions");
+    const int c4 = (lane % LPR) * 4;
+#pragma unroll
+    for (int k = 0; k < RPW / RPI; k++) {
+      const int row = w * RPW + k * RPI + lane / LPR;
+      f32x4 val = *(const f32x4*)(img + row * BN + (c4 ^ (((row >> 2) & 3) << 4)));
+      const long grow = m0 + row;
+      if (grow < M) {
+        if (add_res) {
+          const f32x4 r = *(const f32x4*)(R + grow * Kout + n0 + c4);
+          val += r;
+          if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
+          }
         }
+        // c_padded: row = pixel (n, py-1, px-1) of the 14x14 map -> interior of [N][16][16][Kout]
+        // (its zero ring is written by the ring pass at the top of the kernel)
+        const long orow = c_padded ? padded_row(grow) : grow;
+        *(f32x4*)(Cout + orow * Kout + n0 + c4) = val;
       }
     }
   }

@@ -149,7 +149,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const float* __restrict__ in = prm.in;
   const float* __restrict__ Uq = prm.Uq;
-  const int N = prm.N, C = prm.C, K = prm.K, relu = prm.relu, nTB = prm.nTB;
+  const int N = prm.N, C = prm.C, K = prm.K;
   const unsigned sk_q = prm.sk_q, sk_rem = prm.sk_rem;
   const int ndp = prm.ndp;
 
@@ -200,7 +200,6 @@ wino_f2_fused_kernel(const FusedParams prm) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wt = w >> 1;  // which 16-tile block of the 64
   const int wk = w & 1;   // which 32-channel half of the 64
-  const int totalTiles = N * WINO_TILES;
 
   const unsigned u_off = lane * 16;
   const unsigned u_chunk_stride = (unsigned)(KBLK * U_CHUNK_FLOATS * sizeof(float));

@@ -49,6 +49,7 @@ int main() {
   printf("us per launch, N=128 (M=25088)  |    full noA-DMA noB-DMA   noDMA  noSync noStore  noMFMA\n");
   sweep<4>(A, B, b, s, C, M, 512, 128);  sweep<8>(A, B, b, s, C, M, 512, 128);
   sweep<4>(A, B, b, s, C, M, 128, 512);  sweep<8>(A, B, b, s, C, M, 128, 512);
-  sweep<8>(A, B, b, s, C, M, 1024, 256); sweep<8>(A, B, b, s, C, M, 256, 1024);
+  sweep<4>(A, B, b, s, C, M, 1024, 256); sweep<8>(A, B, b, s, C, M, 1024, 256);
+  sweep<4>(A, B, b, s, C, M, 256, 1024); sweep<8>(A, B, b, s, C, M, 256, 1024);
   return 0;
 }
