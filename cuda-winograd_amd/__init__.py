@@ -158,6 +158,12 @@ def conv3x3_bn_relu(inp: torch.Tensor, U: torch.Tensor, bn_bias: torch.Tensor,
     return out
 
 
+def conv3x3_prepare(N: int, C: int, K: int) -> None:
+    """Allocate the library-owned stream-K scratch of conv3x3_bn_relu for this shape on the current
+    device and stream ahead of time (needed before capturing the call into a HIP graph)."""
+    _check(lib().wino_conv3x3_prepare(int(N), int(C), int(K), _stream()), "wino_conv3x3_prepare")
+
+
 def conv3x3_direct(inp, w_kcrs, bn_bias, bn_scale, relu: bool = True) -> torch.Tensor:
     """Comparator: direct 3x3 conv + BN + ReLU on the GPU (not the product path)."""
     x, w = _dev(inp, "inp"), _dev(w_kcrs, "w_kcrs")

@@ -41,10 +41,6 @@ namespace {
 
 using namespace fused;
 
-// Use the latency kernel while the throughput kernel would start at most this many workgroups
-// (tuned on MI355X).
-constexpr int SMALL_MAX_BIG_WGS = 40;
-
 
 // Position (in floats, 0..7) inside the 8-channel group of the packed filter at which
 // channel `cl` (0..7) of out-channel `kl` (0..63 within the k-block) is stored: the
@@ -278,13 +274,17 @@ static int check_conv3x3(int N, int C, int K) {
   return WINO_OK;
 }
 
-// Two kernels, same arithmetic: the throughput kernel (stream-K over 64-tile x 64-out-channel
-// items, 8-wave workgroups) and, when that would still leave most of the 256 CUs idle, the
-// one-wave-per-SIMD latency kernel (16 tiles x 16 out-channels).  WINO_3X3_ALGO=big|small overrides.
+// Two kernels, same arithmetic: the throughput kernel (64-tile x 64-out-channel items, 8-wave
+// workgroups, whole-item rounds + stream-K tail) and the one-wave-per-SIMD latency kernel (16 tiles
+// x 16 out-channels per workgroup), which wins exactly while its grid fits one round of the CUs:
+// measured 14-15 us vs 27 us (128 channels, N <= 8) and 19-20 us vs 29 us (256 channels, N <= 4),
+// then 27-37 us vs 28-30 us as soon as it needs a second round.  WINO_3X3_ALGO=big|small overrides.
 static bool use_small_kernel(int N, int C, int K) {
-  const int nTB = (N * WINO_TILES + TB - 1) / TB;
-  static const char* algo_env = getenv("WINO_3X3_ALGO");
-  bool small = nTB * (K / KB) <= SMALL_MAX_BIG_WGS && (C % 16) == 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) sk_cus(dev, &cus);
+  const long small_grid = (long)((N * WINO_TILES + 15) / 16) * (K / 16);
+  const char* algo_env = getenv("WINO_3X3_ALGO");
+  bool small = small_grid <= cus && (C % 16) == 0;
   if (algo_env && !strcmp(algo_env, "big")) small = false;
   if (algo_env && !strcmp(algo_env, "small")) small = (C % 16) == 0;
   return small;

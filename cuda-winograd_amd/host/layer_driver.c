@@ -33,7 +33,7 @@
 #define HW WINO_HW
 #define PQ WINO_PQ
 #define MAX_GPUS 64
-#define STEADY_REPS 20
+#define STEADY_REPS 100
 
 /* ---------------------------------------------------------------- configuration */
 static int g_batch = 0, g_gpus = 0, g_quiet = -1;
@@ -156,6 +156,13 @@ static void* job_main(void* arg) {
   /* extension: the same launch repeated back to back on warm caches / clocks (the first,
    * reference-protocol launch above runs right after the uploads) */
   {
+    for (int r = 0; r < 20; ++r) {   /* untimed: lets the clocks ramp before the steady-state loop */
+      if (j->kind == 3)
+        CK(wino_conv3x3_bn_relu(d_in, d_U, d_bias, d_scale, d_out, n, C, K, 1, NULL));
+      else
+        CK(wino_conv1x1_bn(d_in, d_w, d_bias, d_scale, d_out, (long)n * PQ * PQ, C, K, j->relu, NULL));
+    }
+    CK(wino_device_synchronize());
     const uint64_t s0 = getTimeMicroseconds64();
     for (int r = 0; r < STEADY_REPS; ++r) {
       if (j->kind == 3)

@@ -178,7 +178,7 @@ typedef struct {
   long error_cnt;        /* |diff| > 1e-5, reference threshold */
   double flops;          /* algorithmic FLOPs of the layer call (2*N*P*Q*K*C*R*S) */
   int N, gpus;
-  double steady_us;      /* mean of 20 further back-to-back launches (warm), max over GPUs */
+  double steady_us;      /* mean of 100 further back-to-back launches (warm), max over GPUs */
 } wino_driver_result;
 int wino_driver_last_result(wino_driver_result* r);
 

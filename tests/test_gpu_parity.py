@@ -198,6 +198,47 @@ def test_conv3x3_streamk_decompositions_agree(N, C, K, pkg, O, torch_dev, monkey
         assert (a.cpu().numpy()[:, _ring(), :] == 0).all()
 
 
+def test_conv3x3_streams_and_graph(pkg, O, torch_dev):
+    """The stream-K scratch is library-owned, one per (device, stream): launches on two streams
+    must not disturb each other, and after wino_conv3x3_prepare() the launch can be captured into a
+    HIP graph (no allocation inside the capture) and replayed."""
+    torch, dev = torch_dev
+    g = torch.Generator(device="cpu").manual_seed(11)
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
+    xa, xb = mk(96, 16, 16, 256), mk(72, 16, 16, 256)
+    w, s, b = mk(256, 256, 3, 3), mk(256), mk(256)
+    U = pkg.filter_transform_f2(w)
+    ref_a = pkg.conv3x3_bn_relu(xa, U, b, s).clone()
+    ref_b = pkg.conv3x3_bn_relu(xb, U, b, s).clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs_a, outs_b = [], []
+    for _ in range(8):   # interleaved on two streams, both shapes cut items (stream-K tails)
+        with torch.cuda.stream(sa):
+            outs_a.append(pkg.conv3x3_bn_relu(xa, U, b, s))
+        with torch.cuda.stream(sb):
+            outs_b.append(pkg.conv3x3_bn_relu(xb, U, b, s))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref_a) for o in outs_a)
+    assert all(torch.equal(o, ref_b) for o in outs_b)
+    # graph capture on a side stream
+    sg = torch.cuda.Stream()
+    out = torch.empty_like(ref_a)
+    with torch.cuda.stream(sg):
+        pkg.conv3x3_prepare(96, 256, 256)
+        pkg.conv3x3_bn_relu(xa, U, b, s, out=out)   # warm (kernel attributes) outside the capture
+    sg.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    out.zero_()
+    with torch.cuda.graph(graph, stream=sg):
+        pkg.conv3x3_bn_relu(xa, U, b, s, out=out)
+    for _ in range(3):
+        out.fill_(7.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_a)
+
+
 def test_conv3x3_config2_128(pkg, O, torch_dev):
     """BASELINE configs[1]: 128->128, N=128, against the comparator + oracle sample."""
     rng = np.random.RandomState(43)

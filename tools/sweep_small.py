@@ -9,7 +9,7 @@ pkg = ge.load_package(); dev = torch.device("cuda:0")
 for C in (128, 256):
     w=(torch.rand(C,C,3,3)-0.5).to(dev); s=(torch.rand(C)-0.5).to(dev); b=(torch.rand(C)-0.5).to(dev)
     U=pkg.filter_transform_f2(w)
-    for N in (1,2,4,8,16,32,64):
+    for N in (1,2,3,4,6,8,12,16,24,32,48,64,96):
         x=(torch.rand(N,16,16,C)-0.5).to(dev); out=torch.empty(N,16,16,C,device=dev)
         for _ in range(10): pkg.conv3x3_bn_relu(x,U,b,s,out=out)
         torch.cuda.synchronize()
