@@ -40,7 +40,7 @@ oracle/liboracle.so: oracle/cpu_conv.c
 	$(CC) -O3 -march=x86-64-v3 -fPIC -shared -std=gnu11 -o $@ $< -lpthread -lm
 
 # developer tools (ablation of the fused kernel, fp32 MFMA ceiling); not part of the library
-tools: tools/ablate_fused tools/ablate_1x1 tools/mfma_peak
+tools: tools/ablate_fused tools/ablate_1x1 tools/mfma_peak tools/coissue
 tools/ablate_1x1: tools/ablate_1x1.hip $(wildcard $(CSRC)/*.h)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) $< -o $@
 tools/ablate_fused: tools/ablate_fused.hip $(wildcard $(CSRC)/*.h)
@@ -48,10 +48,12 @@ tools/ablate_fused: tools/ablate_fused.hip $(wildcard $(CSRC)/*.h)
 # experiment variants of the ablation tool: make tools/xab_NAME XFLAGS="-DWINO_DMA_MODE=1"
 tools/xab_%: tools/ablate_fused.hip $(wildcard $(CSRC)/*.h)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) $(XFLAGS) tools/ablate_fused.hip -o $@
+tools/coissue: tools/coissue.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 tools/mfma_peak: tools/mfma_peak.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 
 clean:
-	rm -rf $(BUILD) $(LIB) Test oracle/liboracle.so tools/ablate_fused tools/ablate_1x1 tools/mfma_peak
+	rm -rf $(BUILD) $(LIB) Test oracle/liboracle.so tools/ablate_fused tools/ablate_1x1 tools/mfma_peak tools/coissue
 
 .PHONY: all oracle tools clean

@@ -47,7 +47,7 @@ constexpr int U_BYTES = 16 * KB * BC * 4;    // 32768: one filter stage
 constexpr int N_RSTAGE = 2, N_USTAGE = 3;
 constexpr int LDS_BYTES = N_RSTAGE * RAW_BYTES + N_USTAGE * U_BYTES;  // 163840 = all 160 KiB of the CU
 constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
-constexpr int PF = 2;                        // filter-fragment prefetch distance (points)
+constexpr int PF = 2;                        // filter-fragment prefetch distance (points); 2..6 measured equal
 constexpr int SLAB_BYTES = TB * 4 * KB * 4;  // 65536: pre-BN output of one item (64 tiles x 2x2 px x 64 k)
 #ifndef WINO_DMA0
 #define WINO_DMA0 4   // tuned with tools/ablate_fused: 0..4 equal, 6 +1 %, 8 +4 %
@@ -83,9 +83,12 @@ constexpr int lds_n(int q) { return 2 + lds_nr(q); }
 // fragments of point e (requested two steps earlier; for e < 2 before the barrier, which
 // drains lgkmcnt) and, on steps 2,4,6,8, the patch pixels requested at steps e-2, e-1.
 constexpr int lds_wait_count(int e) {
+  // the fragments of point e were requested at step e-PF, before that step's patch reads
   int after = 15;
-  if (e >= 2) after = lds_nr(e - 2) + lds_n(e - 1) + lds_n(e);
-  if (e >= 2 && e <= 8 && (e & 1) == 0) after = lds_n(e) < after ? lds_n(e) : after;
+  if (e >= PF) {
+    after = lds_nr(e - PF);
+    for (int q = e - PF + 1; q <= e; q++) after += lds_n(q);
+  }
   return after > 15 ? 15 : after;
 }
 
@@ -364,7 +367,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
     acc[e][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   P2 v[16];          // V_it at the top of iteration `it`; rewritten in place with V_{it+1}
-  f32x2 bfn[2][2];   // filter fragments of points 0, 1 of the next iteration (requested pre-barrier)
+  f32x2 bfn[PF][2];  // filter fragments of points 0..PF-1 of the next iteration (requested pre-barrier)
 
   // ---- prologue: iterations 0 and 1 in flight; V_0 and the first fragments un-pipelined -----
   d_chunk = c_chunk;
@@ -397,7 +400,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #pragma unroll
     for (int e = 0; e < 16; e++) v_point(v, tmp, e);
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
+    for (int e = 0; e < PF; e++) {
       bfn[e][0] = *(const f32x2*)(smem + b_base[0] + e * 2048);
       bfn[e][1] = *(const f32x2*)(smem + b_base[1] + e * 2048);
     }
@@ -435,8 +438,8 @@ wino_f2_fused_kernel(const FusedParams prm) {
     const char* unxt1 = smem + b_base[1] + us_nxt * U_BYTES;
 
     f32x2 bf[16][2];
-    bf[0][0] = bfn[0][0]; bf[0][1] = bfn[0][1];
-    bf[1][0] = bfn[1][0]; bf[1][1] = bfn[1][1];
+#pragma unroll
+    for (int e = 0; e < PF; e++) { bf[e][0] = bfn[e][0]; bf[e][1] = bfn[e][1]; }
     P2 d[16], tmp[16];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -9,7 +9,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int NT>
+// PAT: 1 = each accumulator twice in a row (dependent back-to-back), 2 = a0 a1 a0 a1 (dependence at
+// distance 2, the fused kernel's order), 4 = a0 a1 a2 a3 a0 a1 a2 a3 (distance 4)
+template <int NT, int PAT = 1>
 __global__ void __launch_bounds__(NT) mfma_loop(const float* __restrict__ in, float* __restrict__ out,
                                                 unsigned long long* __restrict__ stamps, int iters) {
   const int tid = threadIdx.x;
@@ -22,9 +24,13 @@ __global__ void __launch_bounds__(NT) mfma_loop(const float* __restrict__ in, fl
   unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i & 7], b[(i >> 2) & 7], acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i & 7], a[(i >> 2) & 7], acc[i], 0, 0, 0);
+    for (int g = 0; g < 32; g += PAT) {
+#pragma unroll
+      for (int i = g; i < g + PAT; i++)
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i & 7], b[(i >> 2) & 7], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = g; i < g + PAT; i++)
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i & 7], a[(i >> 2) & 7], acc[i], 0, 0, 0);
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -35,15 +41,15 @@ __global__ void __launch_bounds__(NT) mfma_loop(const float* __restrict__ in, fl
   if (tid == 0) { stamps[blockIdx.x * 2] = t1 - t0; stamps[blockIdx.x * 2 + 1] = r1 - r0; }
 }
 
-template <int NT>
+template <int NT, int PAT = 1>
 void run(const float* in, float* out, unsigned long long* st, int blocks, int iters) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(mfma_loop<NT>, dim3(blocks), dim3(NT), 0, 0, in, out, st, iters);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((mfma_loop<NT, PAT>), dim3(blocks), dim3(NT), 0, 0, in, out, st, iters);
   CK(hipDeviceSynchronize());
   const int reps = 20;
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(mfma_loop<NT>, dim3(blocks), dim3(NT), 0, 0, in, out, st, iters);
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((mfma_loop<NT, PAT>), dim3(blocks), dim3(NT), 0, 0, in, out, st, iters);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1000.0 / reps;
@@ -52,8 +58,8 @@ void run(const float* in, float* out, unsigned long long* st, int blocks, int it
   CK(hipMemcpy(h.data(), st, blocks * 16, hipMemcpyDeviceToHost));
   double cyc = 0, rt = 0;
   for (int i = 0; i < blocks; i++) { cyc += h[2 * i]; rt += h[2 * i + 1]; }
-  printf("threads/WG %4d blocks %5d iters %5d : %8.1f us  %7.1f TFLOP/s  in-kernel clock %.3f GHz  cycles/MFMA/SIMD %.1f\n",
-         NT, blocks, iters, us, flops / us / 1e6, cyc / rt * 0.1, (cyc / blocks) / (iters * 64.0 * (NT / 256)));
+  printf("pattern %d  threads/WG %4d blocks %5d iters %5d : %8.1f us  %7.1f TFLOP/s  in-kernel clock %.3f GHz  cycles/MFMA/SIMD %.1f\n",
+         PAT, NT, blocks, iters, us, flops / us / 1e6, cyc / rt * 0.1, (cyc / blocks) / (iters * 64.0 * (NT / 256)));
 }
 
 int main() {
@@ -68,5 +74,9 @@ int main() {
   run<512>(in, out, st, 256, 500);
   run<512>(in, out, st, 256, 2000);
   run<512>(in, out, st, 392, 32);
+  run<256, 2>(in, out, st, 256, 1000);
+  run<512, 2>(in, out, st, 256, 500);
+  run<256, 4>(in, out, st, 256, 1000);
+  run<512, 4>(in, out, st, 256, 500);
   return 0;
 }
