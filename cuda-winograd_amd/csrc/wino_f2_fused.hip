@@ -29,6 +29,7 @@
 // *source* address for the raw patches (the LDS destination of an LDS-DMA is lane-linear)
 // and baked into the packed filter layout for U.
 #include "wino_f2_small_kernel.h"
+#include "wino_f2_fused4_kernel.h"
 
 #include <atomic>
 #include <mutex>
@@ -232,6 +233,7 @@ static int sk_workspace(int dev, hipStream_t s, int G, size_t items, float** sla
 // 125 us vs 151 us for two whole-item rounds; 128 channels 196 items -> G = 196, 43 us vs 51 us
 // for G = 256 (all tail).  An epilogue costs ~2.3 iterations, the tail's hand-off ~4.8.
 constexpr int SK_MIN_ITERS = 8;
+constexpr bool WINO_DEFAULT_FOUR_WAVES = false;
 constexpr double SK_EPILOGUE_ITERS = 2.3, SK_HANDOFF_ITERS = 4.8;
 static double sk_cost(long long items, int nchunks, long long G) {
   const long long ndp = items / G, tail_items = items % G;
@@ -336,6 +338,20 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
   const long long Tt = (long long)(items % (size_t)G) * (C / BC);   // the stream-K tail's iterations
   const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
                            bnBias, bnScale, out, slabs, tickets};
+  // two builds of the same algorithm: 4 waves x 512 registers (one MFMA stream per SIMD) or 8 waves
+  // x 256 registers; WINO_3X3_WAVES=4|8 overrides
+  const char* wv_env = getenv("WINO_3X3_WAVES");
+  const bool four = wv_env ? atoi(wv_env) == 4 : WINO_DEFAULT_FOUR_WAVES;
+  if (four) {
+    static std::atomic<unsigned long long> attr4_done{0};
+    if (!((attr4_done.load() >> (dev & 63)) & 1ull)) {
+      WINO_HIP(hipFuncSetAttribute((const void*)(fused4::wino_f2_fused4_kernel<0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+      attr4_done.fetch_or(1ull << (dev & 63));
+    }
+    hipLaunchKernelGGL((fused4::wino_f2_fused4_kernel<0>), dim3(G), dim3(fused4::NT4), LDS_BYTES, (hipStream_t)s, prm);
+    return launch_status("wino_f2_fused4_kernel");
+  }
   hipLaunchKernelGGL((wino_f2_fused_kernel<0>), dim3(G), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s, prm);
   return launch_status("wino_f2_fused_kernel");
 }

@@ -198,6 +198,29 @@ def test_conv3x3_streamk_decompositions_agree(N, C, K, pkg, O, torch_dev, monkey
         assert (a.cpu().numpy()[:, _ring(), :] == 0).all()
 
 
+def test_conv3x3_four_wave_build(pkg, O, torch_dev, monkeypatch):
+    """The experimental one-wave-per-SIMD build of the throughput kernel (WINO_3X3_WAVES=4:
+    4 waves x 512 registers, accumulators in AGPRs) computes the same
+    function: oracle on a sample, the 8-wave build to rounding, bitwise reproducible."""
+    torch, dev = torch_dev
+    monkeypatch.setenv("WINO_3X3_ALGO", "big")
+    rng = np.random.RandomState(77)
+    N, C, K = 50, 128, 192
+    x, w, s, b = _rand_layer(rng, N, C, K)
+    xt, wt, st, bt = (_t(torch_dev, a) for a in (x, w, s, b))
+    U = pkg.filter_transform_f2(wt)
+    monkeypatch.setenv("WINO_3X3_WAVES", "8")
+    ref = pkg.conv3x3_bn_relu(xt, U, bt, st).clone()
+    monkeypatch.setenv("WINO_3X3_WAVES", "4")
+    got = pkg.conv3x3_bn_relu(xt, U, bt, st).clone()
+    again = pkg.conv3x3_bn_relu(xt, U, bt, st)
+    assert torch.equal(got, again)
+    assert float((got - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    idx = [0, 17, 49]
+    assert O.rel_error(got[idx].cpu().numpy(), O.conv3x3_bn_relu_direct(x[idx], w, s, b)) < TIGHT
+    assert (got.cpu().numpy()[:, _ring(), :] == 0).all()
+
+
 def test_conv3x3_streams_and_graph(pkg, O, torch_dev):
     """The stream-K scratch is library-owned, one per (device, stream): launches on two streams
     must not disturb each other, and after wino_conv3x3_prepare() the launch can be captured into a

@@ -1,7 +1,7 @@
 // Developer tool: prices the parts of the fused Winograd kernel by timing ablated variants
 // (see ABLATE in csrc/wino_f2_fused_kernel.h).  Not part of the library.
 //   hipcc --offload-arch=gfx950 -O3 -Iinclude -Icuda-winograd_amd/csrc tools/ablate_fused.hip -o tools/ablate_fused
-#include "wino_f2_fused_kernel.h"
+#include "wino_f2_fused4_kernel.h"
 
 #include <cstdlib>
 #include <algorithm>
@@ -14,6 +14,7 @@ using namespace wino::fused;
 
 static float* g_slabs;
 static unsigned* g_tickets;
+static int g_waves = 8;    // argv[4]: 4 = the one-wave-per-SIMD build
 static int g_grid = 256;   // logical workgroups (argv[2]); 0 = one whole item per workgroup
 
 static int grid_for(int N, int K) {
@@ -25,6 +26,7 @@ static int grid_for(int N, int K) {
 template <int AB>
 float run(const float* in, const float* U, const float* b, const float* s, float* out, int N, int C, int K, int reps) {
   CK(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<AB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  CK(hipFuncSetAttribute((const void*)(wino::fused4::wino_f2_fused4_kernel<AB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   const int nTB = (N * 49 + TB - 1) / TB;
   const int grid = grid_for(N, K);
   CK(hipMemset(g_tickets, 0, 65536 * 4));   // ablated variants may leave tickets behind
@@ -33,11 +35,13 @@ float run(const float* in, const float* U, const float* b, const float* s, float
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; i++)
-    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
+    if (g_waves == 4) hipLaunchKernelGGL((wino::fused4::wino_f2_fused4_kernel<AB>), dim3(grid), dim3(256), LDS_BYTES, 0, prm);
+    else hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < reps; i++)
-    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
+    if (g_waves == 4) hipLaunchKernelGGL((wino::fused4::wino_f2_fused4_kernel<AB>), dim3(grid), dim3(256), LDS_BYTES, 0, prm);
+    else hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -48,6 +52,7 @@ float run(const float* in, const float* U, const float* b, const float* s, float
 int main(int argc, char** argv) {
   const int C = argc > 1 ? atoi(argv[1]) : 256, K = C;
   if (argc > 2) g_grid = atoi(argv[2]);
+  if (argc > 4) g_waves = atoi(argv[4]);
   CK(hipMalloc(&g_slabs, (size_t)2 * 4096 * SLAB_BYTES));
   CK(hipMalloc(&g_tickets, 65536 * 4));
   std::vector<int> Ns = {1, 83, 128};
@@ -60,7 +65,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(U, h.data(), (size_t)16 * C * K * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b, h.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + K, K * 4, hipMemcpyHostToDevice));
-  if (argc > 3) {  // quick mode: just the product kernel at N = 128, three trials of 50 launches
+  if (argc > 3 && argv[3][0] == 'q') {  // quick mode: just the product kernel at N = 128, three trials of 50 launches
     float t[3];
     for (int i = 0; i < 3; i++) t[i] = run<0>(in, U, b, s, out, 128, C, K, 50);
     std::sort(t, t + 3);
