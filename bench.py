@@ -39,21 +39,25 @@ LAYERS = {
     "conv1x1_1024_256": ("1x1", 1024, 256, True),
     "conv1x1_256_1024": ("1x1", 256, 1024, False),
     "residual_block": ("block", 1024, 256, True),   # configs[4]: 1x1 1024->256, 3x3 256, 1x1 256->1024 + skip
+    # SURVEY section 8f rank 4 (not in the reference): the 3x3 layers of ResNet's other stages
+    "conv3x3_64_56x56": ("3x3", 64, 64, True),
+    "conv3x3_128_28x28": ("3x3", 128, 128, True),
 }
+FEATURE_MAP = {"conv3x3_64_56x56": 56, "conv3x3_128_28x28": 28}   # default 14
 BATCH = 128
 
 
-def algorithmic_flops(kind: str, N: int, C: int, K: int) -> float:
+def algorithmic_flops(kind: str, N: int, C: int, K: int, H: int = 14) -> float:
     if kind == "block":   # C = outer width (1024), K = bottleneck width (256): 436.7 MFLOP / image
         return 2.0 * N * 14 * 14 * (C * K + K * K * 9 + K * C)
-    return 2.0 * N * 14 * 14 * K * C * (9 if kind == "3x3" else 1)
+    return 2.0 * N * H * H * K * C * (9 if kind == "3x3" else 1)
 
 
-def executed_mfma_flops(kind: str, N: int, C: int, K: int) -> float:
-    """FLOPs the MFMA pipes execute: F(2x2,3x3) = 16 points x (N*49 tiles) x C x K x 2."""
+def executed_mfma_flops(kind: str, N: int, C: int, K: int, H: int = 14) -> float:
+    """FLOPs the MFMA pipes execute: F(2x2,3x3) = 16 points x (N*(H/2)^2 tiles) x C x K x 2."""
     if kind == "block":
         return 2.0 * N * 14 * 14 * 2 * C * K + 2.0 * 16 * N * 49 * K * K
-    return 2.0 * 16 * N * 49 * C * K if kind == "3x3" else algorithmic_flops(kind, N, C, K)
+    return 2.0 * 16 * N * (H // 2) ** 2 * C * K if kind == "3x3" else algorithmic_flops(kind, N, C, K)
 
 
 # ------------------------------------------------------------------ distributed plumbing
@@ -193,14 +197,15 @@ def main():
     red_dev = dev if backend == "nccl" else None
 
     kind, C, K, relu = LAYERS[args.layer]
+    H = FEATURE_MAP.get(args.layer, 14)
     N = BATCH
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     rnd = lambda *shape, scale=1.0: ((torch.rand(*shape, generator=g) - 0.5) * scale).to(dev)
     scale_v, bias_v = rnd(K), rnd(K)
     if kind == "3x3":
-        x = rnd(N, 16, 16, C)
+        x = rnd(N, H + 2, H + 2, C)
         U = pkg.filter_transform_f2(rnd(K, C, 3, 3))       # offline, outside the timed region
-        out = torch.empty((N, 16, 16, K), device=dev)
+        out = torch.empty((N, H + 2, H + 2, K), device=dev)
         step = lambda: pkg.conv3x3_bn_relu(x, U, bias_v, scale_v, relu=relu, out=out)
     elif kind == "block":
         x = rnd(N, 14, 14, C)
@@ -259,11 +264,11 @@ def main():
         if t < elapsed:
             elapsed, kernel_ms = t, ev0.elapsed_time(ev1) / args.steps
 
-    flops_rank = algorithmic_flops(kind, N, C, K)
+    flops_rank = algorithmic_flops(kind, N, C, K, H)
     value = flops_rank * world * args.steps / elapsed / 1e12
     ach = flops_rank / (kernel_ms * 1e-3) / 1e12
     line = {
-        "metric": f"effective_tflops_{args.layer}_bn_relu_14x14_N128_fp32" if kind != "1x1"
+        "metric": f"effective_tflops_{args.layer}_bn_relu_{H}x{H}_N128_fp32" if kind != "1x1"
                   else f"effective_tflops_{args.layer}_bn_14x14_N128_fp32",
         "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "trials": args.trials, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
@@ -271,7 +276,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": (f"{kind} conv {C}->{K} + folded BN" + (" + ReLU" if relu else "") +
-                                f", 14x14 (16x16 padded NHWC), N={N} per GPU, fp32") if kind != "block" else
+                                f", {H}x{H} ({H + 2}x{H + 2} padded NHWC), N={N} per GPU, fp32") if kind != "block" else
                                f"ResNet bottleneck 1x1 {C}->{K}, 3x3 {K}->{K}, 1x1 {K}->{C} + skip (BN+ReLU fused), "
                                f"14x14, N={N} per GPU, fp32",
                    "algorithm": {"3x3": "fused Winograd F(2x2,3x3), one HIP launch",
@@ -282,12 +287,12 @@ def main():
                      "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                      "traffic": pmc_traffic(args.layer),
                      "kernel_us": round(kernel_ms * 1e3, 2),
-                     "executed_mfma_frac": round(executed_mfma_flops(kind, N, C, K) /
+                     "executed_mfma_frac": round(executed_mfma_flops(kind, N, C, K, H) /
                                                  (kernel_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                      "note": "achieved = algorithmic (direct-conv) FLOPs per launch / mean launch "
                              "duration from HIP events; Winograd executes 2.25x fewer MFMA FLOPs"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "block":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "block" and H == 14:
         line["cpu_baseline"] = cpu_baseline(kind, C, K, relu, args.cpu_images)
     if world > 1:
         barrier()

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "wino_stream_destroy", "wino_stream_synchronize", "wino_event_create", "wino_event_destroy",
     "wino_event_record", "wino_event_elapsed_ms", "wino_filter_f2_elems", "wino_filter_f2_index",
     "wino_filter_transform_f2", "wino_filter_import_f4", "wino_conv3x3_bn_relu", "wino_conv3x3_prepare",
+    "wino_conv3x3_bn_relu_hw", "wino_conv3x3_prepare_hw", "wino_conv3x3_direct_hw",
     "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_bn_ex", "wino_conv1x1_direct",
     "wino_residual_block", "wino_residual_block_workspace_bytes", "wino_driver_set_batch",
     "wino_driver_set_gpus", "wino_driver_set_quiet", "wino_driver_get_batch",
@@ -74,6 +75,9 @@ def lib() -> ctypes.CDLL:
     L.wino_filter_import_f4.argtypes = [fp, fp, c_int, c_int, c_void_p]
     L.wino_conv3x3_bn_relu.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_prepare.argtypes = [c_int, c_int, c_int, c_void_p]
+    L.wino_conv3x3_bn_relu_hw.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    L.wino_conv3x3_prepare_hw.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p]
+    L.wino_conv3x3_direct_hw.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_direct.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv1x1_bn.argtypes = [fp, fp, fp, fp, fp, c_long, c_int, c_int, c_int, c_void_p]
     L.wino_conv1x1_direct.argtypes = [fp, fp, fp, fp, fp, c_long, c_int, c_int, c_int, c_void_p]
@@ -139,40 +143,48 @@ def filter_import_f4(u36: torch.Tensor) -> torch.Tensor:
 def conv3x3_bn_relu(inp: torch.Tensor, U: torch.Tensor, bn_bias: torch.Tensor,
                     bn_scale: torch.Tensor, relu: bool = True,
                     out: torch.Tensor | None = None) -> torch.Tensor:
-    """inp [N][16][16][C] -> out [N][16][16][K] (interior 14x14, zero ring).  One HIP launch."""
+    """inp [N][H+2][W+2][C] -> out [N][H+2][W+2][K] (interior H x W, zero ring).  One HIP launch.
+    [N][16][16][C] is the reference's 14x14 stage (wino_conv3x3_bn_relu); any other even H, W goes
+    through wino_conv3x3_bn_relu_hw."""
     x = _dev(inp, "inp")
     U = _dev(U, "U")
     b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
-    if x.dim() != 4 or x.shape[1] != 16 or x.shape[2] != 16:
-        raise WinoError("inp must be [N][16][16][C]")
-    N, C, K = int(x.shape[0]), int(x.shape[3]), int(b.numel())
+    if x.dim() != 4 or x.shape[1] < 4 or x.shape[2] < 4:
+        raise WinoError("inp must be [N][H+2][W+2][C]")
+    N, Hp, Wp, C, K = int(x.shape[0]), int(x.shape[1]), int(x.shape[2]), int(x.shape[3]), int(b.numel())
     if U.numel() != 16 * C * K or s.numel() != K:
         raise WinoError("U / bn vectors do not match C, K")
     if out is None:
-        out = torch.empty((N, 16, 16, K), dtype=torch.float32, device=x.device)
-    elif tuple(out.shape) != (N, 16, 16, K) or not out.is_contiguous():
-        raise WinoError("out must be a contiguous [N][16][16][K] tensor")
-    _check(lib().wino_conv3x3_bn_relu(x.data_ptr(), U.data_ptr(), b.data_ptr(), s.data_ptr(),
-                                      out.data_ptr(), N, C, K, int(relu), _stream()),
-           "wino_conv3x3_bn_relu")
+        out = torch.empty((N, Hp, Wp, K), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (N, Hp, Wp, K) or not out.is_contiguous():
+        raise WinoError("out must be a contiguous [N][H+2][W+2][K] tensor")
+    if Hp == 16 and Wp == 16:
+        _check(lib().wino_conv3x3_bn_relu(x.data_ptr(), U.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                          out.data_ptr(), N, C, K, int(relu), _stream()),
+               "wino_conv3x3_bn_relu")
+    else:
+        _check(lib().wino_conv3x3_bn_relu_hw(x.data_ptr(), U.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                             out.data_ptr(), N, Hp - 2, Wp - 2, C, K, int(relu), _stream()),
+               "wino_conv3x3_bn_relu_hw")
     return out
 
 
-def conv3x3_prepare(N: int, C: int, K: int) -> None:
+def conv3x3_prepare(N: int, C: int, K: int, H: int = 14, W: int = 14) -> None:
     """Allocate the library-owned stream-K scratch of conv3x3_bn_relu for this shape on the current
     device and stream ahead of time (needed before capturing the call into a HIP graph)."""
-    _check(lib().wino_conv3x3_prepare(int(N), int(C), int(K), _stream()), "wino_conv3x3_prepare")
+    _check(lib().wino_conv3x3_prepare_hw(int(N), int(H), int(W), int(C), int(K), _stream()),
+           "wino_conv3x3_prepare_hw")
 
 
 def conv3x3_direct(inp, w_kcrs, bn_bias, bn_scale, relu: bool = True) -> torch.Tensor:
-    """Comparator: direct 3x3 conv + BN + ReLU on the GPU (not the product path)."""
+    """Comparator: direct 3x3 conv + BN + ReLU on the GPU (not the product path); any H, W."""
     x, w = _dev(inp, "inp"), _dev(w_kcrs, "w_kcrs")
     b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
-    N, C, K = int(x.shape[0]), int(x.shape[3]), int(w.shape[0])
-    out = torch.empty((N, 16, 16, K), dtype=torch.float32, device=x.device)
-    _check(lib().wino_conv3x3_direct(x.data_ptr(), w.data_ptr(), b.data_ptr(), s.data_ptr(),
-                                     out.data_ptr(), N, C, K, int(relu), _stream()),
-           "wino_conv3x3_direct")
+    N, Hp, Wp, C, K = int(x.shape[0]), int(x.shape[1]), int(x.shape[2]), int(x.shape[3]), int(w.shape[0])
+    out = torch.empty((N, Hp, Wp, K), dtype=torch.float32, device=x.device)
+    _check(lib().wino_conv3x3_direct_hw(x.data_ptr(), w.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                        out.data_ptr(), N, Hp - 2, Wp - 2, C, K, int(relu), _stream()),
+           "wino_conv3x3_direct_hw")
     return out
 
 

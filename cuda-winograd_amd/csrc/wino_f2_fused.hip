@@ -261,16 +261,21 @@ static int sk_grid(int dev, long long items, int nchunks, int* G) {
   return WINO_OK;
 }
 
-static int check_conv3x3(int N, int C, int K) {
+static int check_conv3x3(int N, int H, int W, int C, int K) {
   if (int rc = check_ck(C, K)) return rc;
-  // the kernels address the input with 32-bit byte offsets
-  if (N < 1 || (size_t)N * WINO_HW * WINO_HW * (size_t)(C > K ? C : K) * sizeof(float) >= (1ull << 32)) {
+  if (H < 2 || W < 2 || (H & 1) || (W & 1) || H > 4094 || W > 4094) {
+    set_error("unsupported feature map %dx%d (need even H, W >= 2)", H, W);
+    return WINO_E_SHAPE;
+  }
+  // the kernels address the tensors with 32-bit byte offsets
+  if (N < 1 || (size_t)N * (H + 2) * (W + 2) * (size_t)(C > K ? C : K) * sizeof(float) >= (1ull << 32)) {
     set_error("bad batch N=%d (input/output must stay below 4 GiB)", N);
     return WINO_E_SHAPE;
   }
   // stream-K bookkeeping is 32-bit: chunk iterations in all
-  if ((long long)((N * WINO_TILES + TB - 1) / TB) * (K / KB) * (C / BC) >= (1ll << 31)) {
-    set_error("N=%d C=%d K=%d: too many chunk iterations for one launch", N, C, K);
+  const long long tiles = (long long)N * (H / 2) * (W / 2);
+  if (((tiles + TB - 1) / TB) * (K / KB) * (C / BC) >= (1ll << 31)) {
+    set_error("N=%d %dx%d C=%d K=%d: too many chunk iterations for one launch", N, H, W, C, K);
     return WINO_E_SHAPE;
   }
   return WINO_OK;
@@ -278,10 +283,12 @@ static int check_conv3x3(int N, int C, int K) {
 
 // Two kernels, same arithmetic: the throughput kernel (64-tile x 64-out-channel items, 8-wave
 // workgroups, whole-item rounds + stream-K tail) and the one-wave-per-SIMD latency kernel (16 tiles
-// x 16 out-channels per workgroup), which wins exactly while its grid fits one round of the CUs:
-// measured 14-15 us vs 27 us (128 channels, N <= 8) and 19-20 us vs 29 us (256 channels, N <= 4),
-// then 27-37 us vs 28-30 us as soon as it needs a second round.  WINO_3X3_ALGO=big|small overrides.
-static bool use_small_kernel(int N, int C, int K) {
+// x 16 out-channels per workgroup; 14x14 maps only), which wins exactly while its grid fits one
+// round of the CUs: measured 14-15 us vs 27 us (128 channels, N <= 8) and 19-20 us vs 29 us (256
+// channels, N <= 4), then 27-37 us vs 28-30 us as soon as it needs a second round.
+// WINO_3X3_ALGO=big|small overrides.
+static bool use_small_kernel(int N, int H, int W, int C, int K) {
+  if (H != WINO_PQ || W != WINO_PQ) return false;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) sk_cus(dev, &cus);
   const long small_grid = (long)((N * WINO_TILES + 15) / 16) * (K / 16);
@@ -292,54 +299,61 @@ static bool use_small_kernel(int N, int C, int K) {
   return small;
 }
 
-extern "C" {
-
-int wino_conv3x3_prepare(int N, int C, int K, wino_stream_t s) {
-  if (int rc = check_conv3x3(N, C, K)) return rc;
-  if (use_small_kernel(N, C, K)) return WINO_OK;
+static int conv3x3_prepare(int N, int H, int W, int C, int K, hipStream_t s) {
+  if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
+  if (use_small_kernel(N, H, W, C, K)) return WINO_OK;
   int dev = 0;
   WINO_HIP(hipGetDevice(&dev));
-  const int nTB = (N * WINO_TILES + TB - 1) / TB;
+  const int nTB = (int)(((long long)N * (H / 2) * (W / 2) + TB - 1) / TB);
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;
   if (int rc = sk_grid(dev, (long long)items, C / BC, &G)) return rc;
   float* slabs;
   unsigned* tickets;
-  return sk_workspace(dev, (hipStream_t)s, G, items, &slabs, &tickets);
+  return sk_workspace(dev, s, G, items, &slabs, &tickets);
 }
 
-int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
-                         const float* bnScale, float* out, int N, int C, int K, int relu,
-                         wino_stream_t s) {
-  if (!in || !U || !bnBias || !bnScale || !out) { set_error("NULL pointer"); return WINO_E_ARG; }
-  if (int rc = check_conv3x3(N, C, K)) return rc;
-  const int nTB = (N * WINO_TILES + TB - 1) / TB;
-  if (use_small_kernel(N, C, K)) {
-    const int nT16 = (N * WINO_TILES + 15) / 16;
-    hipLaunchKernelGGL(wino_f2_small_kernel, dim3(nT16, K / 16), dim3(64 * SMALL_WAVES), 0, (hipStream_t)s, in, U,
-                       bnBias, bnScale, out, N, C, K, relu);
-    return launch_status("wino_f2_small_kernel");
-  }
+template <bool GEN>
+static int launch_fused(const FusedParams& prm, int G, int dev, hipStream_t s) {
   // raise the dynamic-LDS cap (all 160 KB of the CU) once per device
   static std::atomic<unsigned long long> attr_done{0};
-  int dev = 0;
-  WINO_HIP(hipGetDevice(&dev));
   if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
-    WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<0>),
+    WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<0, GEN>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done.fetch_or(1ull << (dev & 63));
   }
+  hipLaunchKernelGGL((wino_f2_fused_kernel<0, GEN>), dim3(G), dim3(NTHREADS), LDS_BYTES, s, prm);
+  return launch_status("wino_f2_fused_kernel");
+}
+
+static int conv3x3_launch(const float* in, const float* U, const float* bnBias, const float* bnScale,
+                          float* out, int N, int H, int W, int C, int K, int relu, hipStream_t s) {
+  if (!in || !U || !bnBias || !bnScale || !out) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
+  const bool fixed14 = H == WINO_PQ && W == WINO_PQ;
+  if (use_small_kernel(N, H, W, C, K)) {
+    const int nT16 = (N * WINO_TILES + 15) / 16;
+    hipLaunchKernelGGL(wino_f2_small_kernel, dim3(nT16, K / 16), dim3(64 * SMALL_WAVES), 0, s, in, U,
+                       bnBias, bnScale, out, N, C, K, relu);
+    return launch_status("wino_f2_small_kernel");
+  }
+  int dev = 0;
+  WINO_HIP(hipGetDevice(&dev));
+  const unsigned tiles_x = (unsigned)(W / 2), tiles = (unsigned)(H / 2) * tiles_x;
+  const int nTB = (int)(((long long)N * tiles + TB - 1) / TB);
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;
   if (int rc = sk_grid(dev, (long long)items, C / BC, &G)) return rc;
   float* slabs = nullptr;
   unsigned* tickets = nullptr;
-  if (int rc = sk_workspace(dev, (hipStream_t)s, G, items, &slabs, &tickets)) return rc;
+  if (int rc = sk_workspace(dev, s, G, items, &slabs, &tickets)) return rc;
   const long long Tt = (long long)(items % (size_t)G) * (C / BC);   // the stream-K tail's iterations
+  const Geo geo = {H + 2, W + 2, tiles, tiles_x, make_fastdiv(tiles), make_fastdiv(tiles_x)};
   const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
-                           bnBias, bnScale, out, slabs, tickets};
-  // two builds of the same algorithm: 4 waves x 512 registers (one MFMA stream per SIMD) or 8 waves
-  // x 256 registers; WINO_3X3_WAVES=4|8 overrides
+                           geo, bnBias, bnScale, out, slabs, tickets};
+  if (!fixed14) return launch_fused<true>(prm, G, dev, s);
+  // 14x14: two builds of the same algorithm, 8 waves x 256 registers (default) or the experimental
+  // 4 waves x 512 registers (one MFMA stream per SIMD); WINO_3X3_WAVES=4|8 overrides
   const char* wv_env = getenv("WINO_3X3_WAVES");
   const bool four = wv_env ? atoi(wv_env) == 4 : WINO_DEFAULT_FOUR_WAVES;
   if (four) {
@@ -349,11 +363,32 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
       attr4_done.fetch_or(1ull << (dev & 63));
     }
-    hipLaunchKernelGGL((fused4::wino_f2_fused4_kernel<0>), dim3(G), dim3(fused4::NT4), LDS_BYTES, (hipStream_t)s, prm);
+    hipLaunchKernelGGL((fused4::wino_f2_fused4_kernel<0>), dim3(G), dim3(fused4::NT4), LDS_BYTES, s, prm);
     return launch_status("wino_f2_fused4_kernel");
   }
-  hipLaunchKernelGGL((wino_f2_fused_kernel<0>), dim3(G), dim3(NTHREADS), LDS_BYTES, (hipStream_t)s, prm);
-  return launch_status("wino_f2_fused_kernel");
+  return launch_fused<false>(prm, G, dev, s);
+}
+
+extern "C" {
+
+int wino_conv3x3_prepare(int N, int C, int K, wino_stream_t s) {
+  return conv3x3_prepare(N, WINO_PQ, WINO_PQ, C, K, (hipStream_t)s);
+}
+
+int wino_conv3x3_prepare_hw(int N, int H, int W, int C, int K, wino_stream_t s) {
+  return conv3x3_prepare(N, H, W, C, K, (hipStream_t)s);
+}
+
+int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
+                         const float* bnScale, float* out, int N, int C, int K, int relu,
+                         wino_stream_t s) {
+  return conv3x3_launch(in, U, bnBias, bnScale, out, N, WINO_PQ, WINO_PQ, C, K, relu, (hipStream_t)s);
+}
+
+int wino_conv3x3_bn_relu_hw(const float* in, const float* U, const float* bnBias,
+                            const float* bnScale, float* out, int N, int H, int W, int C, int K,
+                            int relu, wino_stream_t s) {
+  return conv3x3_launch(in, U, bnBias, bnScale, out, N, H, W, C, K, relu, (hipStream_t)s);
 }
 
 }  // extern "C"

@@ -104,6 +104,44 @@ __device__ __forceinline__ TileCoord decode_tile(int g) {
   return t;
 }
 
+// Feature-map geometry of a launch: H x W outputs (both even) = (H/2) x (W/2) tiles per image, inside
+// padded (H+2) x (W+2) tensors.  The reference's 14x14 stage is a compile-time specialisation
+// (GEN = false: the divisions by 49 and 7 fold into multiplies); other sizes (ResNet's 56x56 and
+// 28x28 stages) carry the numbers in the kernel arguments, with the two
+// divisors as Granlund-Montgomery multipliers: q = (t + ((n - t) >> 1)) >> (l - 1), t = umulhi(m, n).
+struct FastDiv {
+  unsigned m, l;   // l = 0: divisor 1
+};
+__host__ __device__ inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f = {0u, 0u};
+  if (d <= 1) return f;
+  unsigned l = 0;
+  while ((1ull << l) < d) l++;
+  f.l = l;
+  f.m = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1ull);
+  return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) {
+  if (f.l == 0) return n;
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> 1)) >> (f.l - 1);
+}
+struct Geo {
+  int Hp, Wp;              // padded extents
+  unsigned tiles, tiles_x;  // tiles per image, per tile row
+  FastDiv d_tiles, d_tx;
+};
+template <bool GEN>
+__device__ __forceinline__ TileCoord decode_tile_g(int g, const Geo& geo) {
+  if (!GEN) return decode_tile(g);
+  TileCoord t;
+  t.n = (int)fastdiv((unsigned)g, geo.d_tiles);
+  const unsigned rem = (unsigned)g - (unsigned)t.n * geo.tiles;
+  t.ty = (int)fastdiv(rem, geo.d_tx);
+  t.tx = (int)(rem - (unsigned)t.ty * geo.tiles_x);
+  return t;
+}
+
 // Stream-K bookkeeping shared by the kernel and the host (T < 2^31, G <= 65535): logical
 // workgroup l of G owns the iterations [sk_start(l), sk_start(l+1)) of T = q*G + rem, i.e.
 // floor(l*T/G) = l*q + floor(l*rem/G) in 32-bit arithmetic.
@@ -138,6 +176,7 @@ struct FusedParams {
   int N, C, K, relu, nTB;
   int ndp;                     // whole-item rounds: items / gridDim.x
   unsigned sk_q, sk_rem;       // tail: (items % gridDim.x) * C/8 = sk_q * gridDim.x + sk_rem iterations
+  Geo geo;                     // feature-map geometry (read by the GEN = true build only)
   // ---- epilogue only ----
   const float* bnBias;
   const float* bnScale;
@@ -146,7 +185,7 @@ struct FusedParams {
   unsigned* tickets;
 };
 
-template <int ABLATE>
+template <int ABLATE, bool GEN = false>
 __global__ void __launch_bounds__(NTHREADS, 2)
 wino_f2_fused_kernel(const FusedParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,19 +217,21 @@ wino_f2_fused_kernel(const FusedParams prm) {
   // cost more than the tiles' own stores: sparse predicated stores and their address arithmetic.)
   auto ring_pass = [&]() {
     if (ABLATE & 512) return;
+    const unsigned Hp = GEN ? (unsigned)prm.geo.Hp : (unsigned)WINO_HW, Wp = GEN ? (unsigned)prm.geo.Wp : (unsigned)WINO_HW;
+    const unsigned rpx = 2u * Wp + 2u * (Hp - 2u);               // ring pixels per image (60 at 16 x 16)
     const unsigned upp = (unsigned)K >> 2;                       // units per ring pixel
-    const unsigned long long U = (unsigned long long)N * 60u * upp;
+    const unsigned long long U = (unsigned long long)N * rpx * upp;
     const unsigned u_begin = (unsigned)(U * (unsigned)lg / (unsigned)G);
     const unsigned u_end = (unsigned)(U * ((unsigned)lg + 1u) / (unsigned)G);
-    const auto rsrc_ring = make_rsrc(prm.out, (unsigned)((size_t)N * WINO_HW * WINO_HW * K * sizeof(float)));
+    const auto rsrc_ring = make_rsrc(prm.out, (unsigned)((size_t)N * Hp * Wp * K * sizeof(float)));
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     for (unsigned u = u_begin + threadIdx.x; u < u_end; u += NTHREADS) {
       const unsigned pid = u / upp, unit = u - pid * upp;
-      const unsigned n = pid / 60u, q = pid - n * 60u;
-      // q: 0..15 row 0, 16..31 row 15, 32..45 column 0 (rows 1..14), 46..59 column 15
-      const unsigned y = q < 16 ? 0u : q < 32 ? (unsigned)(WINO_HW - 1) : q < 46 ? q - 31u : q - 45u;
-      const unsigned x = q < 16 ? q : q < 32 ? q - 16u : q < 46 ? 0u : (unsigned)(WINO_HW - 1);
-      buf_store16(zero4, rsrc_ring, (((n * WINO_HW + y) * WINO_HW + x) * (unsigned)K + unit * 4u) * (unsigned)sizeof(float), 0);
+      const unsigned n = pid / rpx, q = pid - n * rpx;
+      // q: [0, Wp) row 0, [Wp, 2Wp) the last row, then column 0 and the last column of rows 1..Hp-2
+      const unsigned y = q < Wp ? 0u : q < 2 * Wp ? Hp - 1 : q < 2 * Wp + Hp - 2 ? q - 2 * Wp + 1 : q - 2 * Wp - (Hp - 2) + 1;
+      const unsigned x = q < Wp ? q : q < 2 * Wp ? q - Wp : q < 2 * Wp + Hp - 2 ? 0u : Wp - 1;
+      buf_store16(zero4, rsrc_ring, (((n * Hp + y) * Wp + x) * (unsigned)K + unit * 4u) * (unsigned)sizeof(float), 0);
     }
   };
   if (L <= 0) {   // more workgroups than iterations: this one only has its share of the ring
@@ -207,7 +248,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
   const unsigned u_off = lane * 16;
   const unsigned u_chunk_stride = (unsigned)(KBLK * U_CHUNK_FLOATS * sizeof(float));
   // buffer descriptors (wave-uniform): everything loop-variant goes into the scalar offset
-  const auto rsrc_in = make_rsrc(in, (unsigned)((size_t)N * WINO_HW * WINO_HW * C * sizeof(float)));
+  const auto rsrc_in = make_rsrc(in, (unsigned)((size_t)N * (GEN ? prm.geo.Hp * prm.geo.Wp : WINO_HW * WINO_HW) * C * sizeof(float)));
   const auto rsrc_u = make_rsrc(Uq, (unsigned)((size_t)16 * C * K * sizeof(float)));
 
   // ---- fragment read addresses (launch invariant) -------------------------------
@@ -273,6 +314,13 @@ wino_f2_fused_kernel(const FusedParams prm) {
     asm volatile("" : "+s"(kp));
     return kp;
   };
+  auto load_geo = [](KernargPtr kp) {   // member-wise: the struct lives in the constant address space
+    Geo g;
+    g.Hp = kp->geo.Hp; g.Wp = kp->geo.Wp; g.tiles = kp->geo.tiles; g.tiles_x = kp->geo.tiles_x;
+    g.d_tiles.m = kp->geo.d_tiles.m; g.d_tiles.l = kp->geo.d_tiles.l;
+    g.d_tx.m = kp->geo.d_tx.m; g.d_tx.l = kp->geo.d_tx.l;
+    return g;
+  };
 
   // ---- the DMA stream: walks (item, chunk) linearly, two iterations ahead of the MFMAs ------
   // raw stage layout: [tile 0..63][unit' 0..31] of 16 B; unit' = px'*2 + half'.
@@ -290,7 +338,9 @@ wino_f2_fused_kernel(const FusedParams prm) {
     if (tb != d_tb) {
       d_tb = tb;
       KernargPtr kp = kernarg();
-      const int C = kp->C, totalTiles = kp->N * WINO_TILES;
+      const Geo geo = load_geo(kp);
+      const int Wp = GEN ? geo.Wp : WINO_HW, Hp = GEN ? geo.Hp : WINO_HW;
+      const int C = kp->C, totalTiles = kp->N * (GEN ? (int)geo.tiles : WINO_TILES);
       const int up = lane & 31;
       const int pxp = up >> 1, halfp = up & 1;
 #pragma unroll
@@ -300,9 +350,9 @@ wino_f2_fused_kernel(const FusedParams prm) {
         const int half = halfp ^ ((tl >> 3) & 1);
         int g = tb * TB + tl;
         g = g < totalTiles ? g : totalTiles - 1;  // clamp: padded rows read a valid tile
-        const TileCoord tc = decode_tile(g);
+        const TileCoord tc = decode_tile_g<GEN>(g, geo);
         const int y = 2 * tc.ty + (px >> 2), x = 2 * tc.tx + (px & 3);
-        raw_off[j] = (unsigned)((((size_t)(tc.n * WINO_HW + y) * WINO_HW + x) * C + half * 4) * sizeof(float));
+        raw_off[j] = (unsigned)((((size_t)(tc.n * Hp + y) * Wp + x) * C + half * 4) * sizeof(float));
       }
     }
     d_soff_raw = __builtin_amdgcn_readfirstlane((unsigned)(d_chunk * (BC * sizeof(float))));
@@ -549,13 +599,15 @@ wino_f2_fused_kernel(const FusedParams prm) {
     const int e_t16 = ln & 15, e_h = ln >> 4, e_wt = wv >> 1, e_wk = wv & 1;
     char* wreg = smem + (wv < 4 ? rfree + wv * 8192 : ufree + (wv - 4) * 8192);
     KernargPtr kp = kernarg();
-    const int N = kp->N, K = kp->K, relu = kp->relu, KBLK = K >> 6, totalTiles = N * WINO_TILES;
+    const Geo geo = load_geo(kp);
+    const int Wp = GEN ? geo.Wp : WINO_HW, Hp = GEN ? geo.Hp : WINO_HW;
+    const int N = kp->N, K = kp->K, relu = kp->relu, KBLK = K >> 6, totalTiles = N * (GEN ? (int)geo.tiles : WINO_TILES);
     const unsigned sk_q = kp->sk_q, sk_rem = kp->sk_rem;
     const int tail_item0 = kp->ndp * G;
     const float* bnBias = kp->bnBias;
     const float* bnScale = kp->bnScale;
     unsigned* tickets = kp->tickets;
-    const auto rsrc_out = make_rsrc(kp->out, (unsigned)((size_t)N * WINO_HW * WINO_HW * K * sizeof(float)));
+    const auto rsrc_out = make_rsrc(kp->out, (unsigned)((size_t)N * Hp * Wp * K * sizeof(float)));
     const auto rsrc_slab = make_rsrc(kp->slabs, (unsigned)((size_t)2 * G * SLAB_BYTES));
     const unsigned slab_voff = (unsigned)((wv * 8 * 64 + ln) * 16);
 
@@ -706,10 +758,10 @@ wino_f2_fused_kernel(const FusedParams prm) {
         const f32x4 val = *(const f32x4*)(wreg + ep_rbase[i >> 1] + i * 1024);
         const int g = tb * TB + e_wt * 16 + 2 * i + (ln >> 5);
         const bool live = g < totalTiles;
-        const TileCoord tc = decode_tile(live ? g : 0);
+        const TileCoord tc = decode_tile_g<GEN>(live ? g : 0, geo);
         const int py = 1 + 2 * tc.ty + pa, pxx = 1 + 2 * tc.tx + pb;
-        const unsigned img = (unsigned)(tc.n * WINO_HW * WINO_HW);
-        if (live) buf_store16(val, rsrc_out, (unsigned)((img + py * WINO_HW + pxx) * K * sizeof(float)) + kbyte, 0);
+        const unsigned img = (unsigned)(tc.n * Hp * Wp);
+        if (live) buf_store16(val, rsrc_out, (unsigned)((img + py * Wp + pxx) * K * sizeof(float)) + kbyte, 0);
       }
     }
     phase(3);

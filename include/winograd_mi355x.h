@@ -113,11 +113,24 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
  * the capture is not allowed.  Optional otherwise. */
 int wino_conv3x3_prepare(int N, int C, int K, wino_stream_t s);
 
+/* Other feature-map sizes (ResNet's 56x56 and 28x28 stages; the reference hard-codes
+ * 14x14): H x W outputs, both even, in [N][H+2][W+2][C], out [N][H+2][W+2][K] with the result at
+ * [1..H][1..W] and the ring written as 0.  Same kernel, same packed filters; H = W = 14 is exactly
+ * wino_conv3x3_bn_relu.  The latency kernel for tiny batches exists for 14x14 only. */
+int wino_conv3x3_bn_relu_hw(const float* in, const float* U, const float* bnBias,
+                            const float* bnScale, float* out, int N, int H, int W, int C, int K,
+                            int relu, wino_stream_t s);
+int wino_conv3x3_prepare_hw(int N, int H, int W, int C, int K, wino_stream_t s);
+
 /* Independent comparator: direct (non-Winograd) 3x3 conv + BN + ReLU on the GPU,
  * w_kcrs [K][C][3][3]; same in/out layout as above.  Slow by design. */
 int wino_conv3x3_direct(const float* in, const float* w_kcrs, const float* bnBias,
                         const float* bnScale, float* out, int N, int C, int K, int relu,
                         wino_stream_t s);
+
+int wino_conv3x3_direct_hw(const float* in, const float* w_kcrs, const float* bnBias,
+                           const float* bnScale, float* out, int N, int H, int W, int C, int K,
+                           int relu, wino_stream_t s);
 
 /* ---- 1x1 conv as GEMM + folded BN (+ReLU) --------------------------------------
  * A [M][Cin] (M = N*196 pixels, HWC flat), B [Cin][Kout] row-major, C [M][Kout].

@@ -67,29 +67,31 @@ P = Q = 14   # output extent
 # (what the reference's cuDNN half computes: Kernel128_winograd.cu:352,384-399)
 # --------------------------------------------------------------------------
 def im2col_3x3(inp: np.ndarray) -> np.ndarray:
-    """[N,16,16,C] -> [N*196, 9*C] with column order (r, s, c)."""
-    N, _, _, C = inp.shape
-    cols = np.empty((N, P, Q, 3, 3, C), dtype=inp.dtype)
+    """[N,Hp,Wp,C] -> [N*(Hp-2)*(Wp-2), 9*C] with column order (r, s, c); the reference's case is
+    Hp = Wp = 16."""
+    N, Hp, Wp, C = inp.shape
+    p, q = Hp - 2, Wp - 2
+    cols = np.empty((N, p, q, 3, 3, C), dtype=inp.dtype)
     for r in range(3):
         for s in range(3):
-            cols[:, :, :, r, s, :] = inp[:, r:r + P, s:s + Q, :]
-    return cols.reshape(N * P * Q, 9 * C)
+            cols[:, :, :, r, s, :] = inp[:, r:r + p, s:s + q, :]
+    return cols.reshape(N * p * q, 9 * C)
 
 
 def conv3x3_bn_relu_direct(inp, w_kcrs, bn_scale, bn_bias, relu=True, dtype=np.float64):
-    """Valid 3x3 cross-correlation of the 16x16 image, y = relu(scale*conv + bias),
-    written into the interior of a zero [N,16,16,K] buffer (reference output
-    layout, Kernel128_winograd.cu:163)."""
+    """Valid 3x3 cross-correlation of the padded image, y = relu(scale*conv + bias),
+    written into the interior of a zero [N,Hp,Wp,K] buffer (reference output
+    layout, Kernel128_winograd.cu:163; the reference's size is Hp = Wp = 16)."""
     inp = np.asarray(inp, dtype=dtype)
-    N, _, _, C = inp.shape
+    N, Hp, Wp, C = inp.shape
     K = w_kcrs.shape[0]
     wmat = np.asarray(w_kcrs, dtype=dtype).transpose(2, 3, 1, 0).reshape(9 * C, K)  # (r,s,c) x k
     y = im2col_3x3(inp) @ wmat
     y = y * np.asarray(bn_scale, dtype)[None, :] + np.asarray(bn_bias, dtype)[None, :]
     if relu:
         y = np.maximum(y, 0)
-    out = np.zeros((N, H, W, K), dtype=dtype)
-    out[:, 1:1 + P, 1:1 + Q, :] = y.reshape(N, P, Q, K)
+    out = np.zeros((N, Hp, Wp, K), dtype=dtype)
+    out[:, 1:Hp - 1, 1:Wp - 1, :] = y.reshape(N, Hp - 2, Wp - 2, K)
     return out
 
 

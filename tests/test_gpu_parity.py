@@ -198,6 +198,33 @@ def test_conv3x3_streamk_decompositions_agree(N, C, K, pkg, O, torch_dev, monkey
         assert (a.cpu().numpy()[:, _ring(), :] == 0).all()
 
 
+@pytest.mark.parametrize("N,H,W,C,K", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (5, 8, 12, 16, 64),
+                                       (7, 2, 2, 8, 64), (2, 30, 6, 24, 192), (64, 28, 28, 128, 128)])
+def test_conv3x3_other_feature_maps(N, H, W, C, K, pkg, O, torch_dev):
+    """the reference hard-codes ResNet's 14x14 stage; the same kernel
+    with the geometry in its arguments covers even H x W (the 56x56 and 28x28 stages, odd aspect
+    ratios, a single tile).  Oracle on every element for the small cases, oracle on a sample +
+    the direct GPU comparator on every element for the large one; zero ring."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(H * 131 + W)
+    x = (rng.rand(N, H + 2, W + 2, C) - 0.5).astype(np.float32)
+    w = (rng.rand(K, C, 3, 3) - 0.5).astype(np.float32)
+    s = (rng.rand(K) - 0.5).astype(np.float32)
+    b = (rng.rand(K) - 0.5).astype(np.float32)
+    xt, wt, st, bt = (_t(torch_dev, a) for a in (x, w, s, b))
+    U = pkg.filter_transform_f2(wt)
+    got_t = pkg.conv3x3_bn_relu(xt, U, bt, st)
+    again = pkg.conv3x3_bn_relu(xt, U, bt, st)
+    assert torch.equal(got_t, again)
+    got = got_t.cpu().numpy()
+    idx = list(range(N)) if N <= 8 else [0, N // 2, N - 1]
+    assert O.rel_error(got[idx], O.conv3x3_bn_relu_direct(x[idx], w, s, b)) < TIGHT
+    assert O.rel_error(got, pkg.conv3x3_direct(xt, wt, bt, st).cpu().numpy()) < TIGHT
+    ring = np.ones((H + 2, W + 2), bool)
+    ring[1:H + 1, 1:W + 1] = False
+    assert (got[:, ring, :] == 0).all()
+
+
 def test_conv3x3_four_wave_build(pkg, O, torch_dev, monkeypatch):
     """The experimental one-wave-per-SIMD build of the throughput kernel (WINO_3X3_WAVES=4:
     4 waves x 512 registers, accumulators in AGPRs) computes the same
@@ -374,13 +401,22 @@ def test_residual_block(N, C4, Cm, pkg, O, torch_dev):
 
 
 # ------------------------------------------------------------------ errors
+def test_odd_feature_map_raises(pkg, torch_dev):
+    torch, dev = torch_dev
+    x = torch.zeros(1, 9, 9, 8, device=dev)   # 7x7 outputs: odd, not supported
+    U = torch.zeros(16 * 8 * 64, device=dev)
+    v = torch.zeros(64, device=dev)
+    with pytest.raises(pkg.WinoError):
+        pkg.conv3x3_bn_relu(x, U, v, v)
+
+
 def test_bad_shapes_raise(pkg, torch_dev):
     torch, dev = torch_dev
     z = lambda *s: torch.zeros(*s, device=dev)
     with pytest.raises(pkg.WinoError):
         pkg.conv3x3_bn_relu(z(1, 16, 16, 12), z(16 * 12 * 64), z(64), z(64))       # C % 8
     with pytest.raises(pkg.WinoError):
-        pkg.conv3x3_bn_relu(z(1, 14, 14, 16), z(16 * 16 * 64), z(64), z(64))       # not 16x16
+        pkg.conv3x3_bn_relu(z(1, 15, 14, 16), z(16 * 16 * 64), z(64), z(64))       # odd output height
     with pytest.raises(pkg.WinoError):
         pkg.conv1x1_bn(z(8, 48), z(48, 128), z(128), z(128), True)                 # Cin % 32
 
