@@ -42,8 +42,9 @@ LAYERS = {
     # SURVEY section 8f rank 4 (not in the reference): the 3x3 layers of ResNet's other stages
     "conv3x3_64_56x56": ("3x3", 64, 64, True),
     "conv3x3_128_28x28": ("3x3", 128, 128, True),
+    "conv3x3_512_7x7": ("3x3", 512, 512, True),
 }
-FEATURE_MAP = {"conv3x3_64_56x56": 56, "conv3x3_128_28x28": 28}   # default 14
+FEATURE_MAP = {"conv3x3_64_56x56": 56, "conv3x3_128_28x28": 28, "conv3x3_512_7x7": 7}   # default 14
 BATCH = 128
 
 
@@ -57,7 +58,7 @@ def executed_mfma_flops(kind: str, N: int, C: int, K: int, H: int = 14) -> float
     """FLOPs the MFMA pipes execute: F(2x2,3x3) = 16 points x (N*(H/2)^2 tiles) x C x K x 2."""
     if kind == "block":
         return 2.0 * N * 14 * 14 * 2 * C * K + 2.0 * 16 * N * 49 * K * K
-    return 2.0 * 16 * N * (H // 2) ** 2 * C * K if kind == "3x3" else algorithmic_flops(kind, N, C, K)
+    return 2.0 * 16 * N * ((H + 1) // 2) ** 2 * C * K if kind == "3x3" else algorithmic_flops(kind, N, C, K)
 
 
 # ------------------------------------------------------------------ distributed plumbing

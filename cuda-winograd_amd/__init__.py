@@ -149,7 +149,7 @@ def conv3x3_bn_relu(inp: torch.Tensor, U: torch.Tensor, bn_bias: torch.Tensor,
     x = _dev(inp, "inp")
     U = _dev(U, "U")
     b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
-    if x.dim() != 4 or x.shape[1] < 4 or x.shape[2] < 4:
+    if x.dim() != 4 or x.shape[1] < 3 or x.shape[2] < 3:
         raise WinoError("inp must be [N][H+2][W+2][C]")
     N, Hp, Wp, C, K = int(x.shape[0]), int(x.shape[1]), int(x.shape[2]), int(x.shape[3]), int(b.numel())
     if U.numel() != 16 * C * K or s.numel() != K:

@@ -263,8 +263,8 @@ static int sk_grid(int dev, long long items, int nchunks, int* G) {
 
 static int check_conv3x3(int N, int H, int W, int C, int K) {
   if (int rc = check_ck(C, K)) return rc;
-  if (H < 2 || W < 2 || (H & 1) || (W & 1) || H > 4094 || W > 4094) {
-    set_error("unsupported feature map %dx%d (need even H, W >= 2)", H, W);
+  if (H < 1 || W < 1 || H > 4094 || W > 4094) {
+    set_error("unsupported feature map %dx%d", H, W);
     return WINO_E_SHAPE;
   }
   // the kernels address the tensors with 32-bit byte offsets
@@ -273,7 +273,7 @@ static int check_conv3x3(int N, int H, int W, int C, int K) {
     return WINO_E_SHAPE;
   }
   // stream-K bookkeeping is 32-bit: chunk iterations in all
-  const long long tiles = (long long)N * (H / 2) * (W / 2);
+  const long long tiles = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
   if (((tiles + TB - 1) / TB) * (K / KB) * (C / BC) >= (1ll << 31)) {
     set_error("N=%d %dx%d C=%d K=%d: too many chunk iterations for one launch", N, H, W, C, K);
     return WINO_E_SHAPE;
@@ -304,7 +304,7 @@ static int conv3x3_prepare(int N, int H, int W, int C, int K, hipStream_t s) {
   if (use_small_kernel(N, H, W, C, K)) return WINO_OK;
   int dev = 0;
   WINO_HIP(hipGetDevice(&dev));
-  const int nTB = (int)(((long long)N * (H / 2) * (W / 2) + TB - 1) / TB);
+  const int nTB = (int)(((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + TB - 1) / TB);
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;
   if (int rc = sk_grid(dev, (long long)items, C / BC, &G)) return rc;
@@ -339,7 +339,7 @@ static int conv3x3_launch(const float* in, const float* U, const float* bnBias, 
   }
   int dev = 0;
   WINO_HIP(hipGetDevice(&dev));
-  const unsigned tiles_x = (unsigned)(W / 2), tiles = (unsigned)(H / 2) * tiles_x;
+  const unsigned tiles_x = (unsigned)((W + 1) / 2), tiles = (unsigned)((H + 1) / 2) * tiles_x;
   const int nTB = (int)(((long long)N * tiles + TB - 1) / TB);
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;

@@ -104,7 +104,7 @@ __device__ __forceinline__ TileCoord decode_tile(int g) {
   return t;
 }
 
-// Feature-map geometry of a launch: H x W outputs (both even) = (H/2) x (W/2) tiles per image, inside
+// Feature-map geometry of a launch: H x W outputs = ceil(H/2) x ceil(W/2) tiles per image, inside
 // padded (H+2) x (W+2) tensors.  The reference's 14x14 stage is a compile-time specialisation
 // (GEN = false: the divisions by 49 and 7 fold into multiplies); other sizes (ResNet's 56x56 and
 // 28x28 stages) carry the numbers in the kernel arguments, with the two
@@ -761,7 +761,12 @@ wino_f2_fused_kernel(const FusedParams prm) {
         const TileCoord tc = decode_tile_g<GEN>(live ? g : 0, geo);
         const int py = 1 + 2 * tc.ty + pa, pxx = 1 + 2 * tc.tx + pb;
         const unsigned img = (unsigned)(tc.n * Hp * Wp);
-        if (live) buf_store16(val, rsrc_out, (unsigned)((img + py * Wp + pxx) * K * sizeof(float)) + kbyte, 0);
+        // (odd H or W: the last tile row / column computes one output row / column too many, from
+        //  patch rows that belong to the next image row or lie past the tensor -- the descriptor's
+        //  range check returns 0 there; a Winograd output only depends on its own 3x3 window, so
+        //  the kept outputs are unaffected, and the surplus ones must not reach the ring)
+        const bool keep = live && (!GEN || (py <= Hp - 2 && pxx <= Wp - 2));
+        if (keep) buf_store16(val, rsrc_out, (unsigned)((img + py * Wp + pxx) * K * sizeof(float)) + kbyte, 0);
       }
     }
     phase(3);

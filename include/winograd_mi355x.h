@@ -114,8 +114,9 @@ int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
 int wino_conv3x3_prepare(int N, int C, int K, wino_stream_t s);
 
 /* Other feature-map sizes (ResNet's 56x56 and 28x28 stages; the reference hard-codes
- * 14x14): H x W outputs, both even, in [N][H+2][W+2][C], out [N][H+2][W+2][K] with the result at
- * [1..H][1..W] and the ring written as 0.  Same kernel, same packed filters; H = W = 14 is exactly
+ * 14x14): H x W outputs (odd sizes such as the 7x7 stage included: the last tile row / column is
+ * clipped), in [N][H+2][W+2][C], out [N][H+2][W+2][K] with the result at [1..H][1..W] and the ring
+ * written as 0.  Same kernel, same packed filters; H = W = 14 is exactly
  * wino_conv3x3_bn_relu.  The latency kernel for tiny batches exists for 14x14 only. */
 int wino_conv3x3_bn_relu_hw(const float* in, const float* U, const float* bnBias,
                             const float* bnScale, float* out, int N, int H, int W, int C, int K,

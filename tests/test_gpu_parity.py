@@ -199,11 +199,12 @@ def test_conv3x3_streamk_decompositions_agree(N, C, K, pkg, O, torch_dev, monkey
 
 
 @pytest.mark.parametrize("N,H,W,C,K", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (5, 8, 12, 16, 64),
-                                       (7, 2, 2, 8, 64), (2, 30, 6, 24, 192), (64, 28, 28, 128, 128)])
+                                       (7, 2, 2, 8, 64), (2, 30, 6, 24, 192), (64, 28, 28, 128, 128),
+                                       (9, 7, 7, 512, 512), (4, 1, 1, 8, 64), (3, 5, 8, 16, 64), (2, 13, 3, 40, 128)])
 def test_conv3x3_other_feature_maps(N, H, W, C, K, pkg, O, torch_dev):
     """the reference hard-codes ResNet's 14x14 stage; the same kernel
-    with the geometry in its arguments covers even H x W (the 56x56 and 28x28 stages, odd aspect
-    ratios, a single tile).  Oracle on every element for the small cases, oracle on a sample +
+    with the geometry in its arguments covers any H x W (the 56x56, 28x28 and 7x7 stages, odd
+    sizes whose last tile row / column is clipped, odd aspect ratios, a single tile or pixel).  Oracle on every element for the small cases, oracle on a sample +
     the direct GPU comparator on every element for the large one; zero ring."""
     torch, dev = torch_dev
     rng = np.random.RandomState(H * 131 + W)
@@ -401,22 +402,13 @@ def test_residual_block(N, C4, Cm, pkg, O, torch_dev):
 
 
 # ------------------------------------------------------------------ errors
-def test_odd_feature_map_raises(pkg, torch_dev):
-    torch, dev = torch_dev
-    x = torch.zeros(1, 9, 9, 8, device=dev)   # 7x7 outputs: odd, not supported
-    U = torch.zeros(16 * 8 * 64, device=dev)
-    v = torch.zeros(64, device=dev)
-    with pytest.raises(pkg.WinoError):
-        pkg.conv3x3_bn_relu(x, U, v, v)
-
-
 def test_bad_shapes_raise(pkg, torch_dev):
     torch, dev = torch_dev
     z = lambda *s: torch.zeros(*s, device=dev)
     with pytest.raises(pkg.WinoError):
         pkg.conv3x3_bn_relu(z(1, 16, 16, 12), z(16 * 12 * 64), z(64), z(64))       # C % 8
     with pytest.raises(pkg.WinoError):
-        pkg.conv3x3_bn_relu(z(1, 15, 14, 16), z(16 * 16 * 64), z(64), z(64))       # odd output height
+        pkg.conv3x3_bn_relu(z(1, 2, 14, 16), z(16 * 16 * 64), z(64), z(64))        # no room for one output row
     with pytest.raises(pkg.WinoError):
         pkg.conv1x1_bn(z(8, 48), z(48, 128), z(128), z(128), True)                 # Cin % 32
 
