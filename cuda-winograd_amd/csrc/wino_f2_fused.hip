@@ -256,7 +256,7 @@ static int sk_grid(int dev, long long items, int nchunks, int* G) {
   if (g < 1) g = 1;
   if (items <= cus && sk_cost(items, nchunks, items) <= sk_cost(items, nchunks, g)) g = items;
   if (g_env && atoi(g_env) >= 1) g = atoi(g_env);
-  if (g > 65535) g = 65535;
+  if (g > 16384) g = 16384;   // 2 * G slabs of 64 KB must stay below the 4 GiB a buffer descriptor spans
   *G = (int)g;
   return WINO_OK;
 }
