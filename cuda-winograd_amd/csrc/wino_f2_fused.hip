@@ -244,9 +244,13 @@ static double sk_cost(long long items, int nchunks, long long G) {
   }
   return c;
 }
+static int sk_grid_for(int cus, long long items, int nchunks, int* G);
 static int sk_grid(int dev, long long items, int nchunks, int* G) {
   int cus = 0;
   if (int rc = sk_cus(dev, &cus)) return rc;
+  return sk_grid_for(cus, items, nchunks, G);
+}
+static int sk_grid_for(int cus, long long items, int nchunks, int* G) {
   const char* g_env = getenv("WINO_SK_GRID");        // developer overrides, read per call so that
   const char* m_env = getenv("WINO_SK_MIN_ITERS");   // tests can sweep the decomposition
   const int min_iters = m_env && atoi(m_env) > 0 ? atoi(m_env) : SK_MIN_ITERS;
@@ -370,6 +374,21 @@ static int conv3x3_launch(const float* in, const float* U, const float* bnBias, 
 }
 
 extern "C" {
+
+int wino_conv3x3_plan(int N, int H, int W, int C, int K, int cus, int* grid, int* rounds, long* tail_iters,
+                      int* iters_per_item) {
+  if (!grid || !rounds || !tail_iters || !iters_per_item || cus < 1) { set_error("bad argument"); return WINO_E_ARG; }
+  if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
+  const long long nTB = ((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + TB - 1) / TB;
+  const long long items = nTB * (K / KB);
+  int G = 0;
+  if (int rc = sk_grid_for(cus, items, C / BC, &G)) return rc;
+  *grid = G;
+  *rounds = (int)(items / G);
+  *tail_iters = (long)((items % G) * (C / BC));
+  *iters_per_item = C / BC;
+  return WINO_OK;
+}
 
 int wino_conv3x3_prepare(int N, int C, int K, wino_stream_t s) {
   return conv3x3_prepare(N, WINO_PQ, WINO_PQ, C, K, (hipStream_t)s);

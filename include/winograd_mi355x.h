@@ -123,6 +123,13 @@ int wino_conv3x3_bn_relu_hw(const float* in, const float* U, const float* bnBias
                             int relu, wino_stream_t s);
 int wino_conv3x3_prepare_hw(int N, int H, int W, int C, int K, wino_stream_t s);
 
+/* Host-side only (no GPU needed): the launch plan of the throughput kernel on a device with `cus`
+ * compute units -- `grid` logical workgroups run `rounds` whole items each (item = 64 tiles x 64
+ * out-channels, `iters_per_item` = C/8 chunk iterations) and share `tail_iters` further iterations
+ * as a stream-K tail: workgroup l takes tail iterations [l*tail_iters/grid, (l+1)*tail_iters/grid). */
+int wino_conv3x3_plan(int N, int H, int W, int C, int K, int cus, int* grid, int* rounds, long* tail_iters,
+                      int* iters_per_item);
+
 /* Independent comparator: direct (non-Winograd) 3x3 conv + BN + ReLU on the GPU,
  * w_kcrs [K][C][3][3]; same in/out layout as above.  Slow by design. */
 int wino_conv3x3_direct(const float* in, const float* w_kcrs, const float* bnBias,

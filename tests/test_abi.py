@@ -148,3 +148,65 @@ def test_packed_filter_index_is_a_bijection(pkg):
             sl = idx[:, 8 * chunk:8 * chunk + 8, 64 * kb:64 * kb + 64]
             assert sl.max() - sl.min() == 16 * 8 * 64 - 1 and sl.min() % 8192 == 0
     assert L.wino_filter_f2_index(C, K, 16, 0, 0) == -1 and L.wino_filter_f2_index(C, K, 0, C, 0) == -1
+
+
+# ------------------------------------------------------------------ launch plan (host logic, no GPU)
+def _plan(pkg, N, H, W, C, K, cus):
+    L = pkg.lib()
+    g, r, it = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    t = ctypes.c_long()
+    rc = L.wino_conv3x3_plan(N, H, W, C, K, cus, ctypes.byref(g), ctypes.byref(r), ctypes.byref(t), ctypes.byref(it))
+    assert rc == 0, L.wino_last_error_string()
+    return g.value, r.value, t.value, it.value
+
+
+@pytest.mark.parametrize("N,H,W,C,K,cus", [
+    (128, 14, 14, 256, 256, 256),   # the headline: 392 items on 256 CUs
+    (128, 14, 14, 128, 128, 256),   # 196 items: fewer than CUs
+    (1024, 14, 14, 256, 256, 256),  # many rounds
+    (32, 14, 14, 256, 256, 256), (1, 14, 14, 8, 64, 256), (128, 56, 56, 64, 64, 256),
+    (128, 7, 7, 512, 512, 304), (5, 28, 28, 128, 192, 64), (17, 14, 14, 128, 256, 8), (3, 2, 2, 8, 64, 1),
+])
+def test_launch_plan_covers_every_iteration_once(N, H, W, C, K, cus, pkg, monkeypatch):
+    """The throughput kernel's work decomposition, replayed on the host: `rounds` whole items per
+    logical workgroup plus an evenly cut stream-K tail must cover every (item, chunk) iteration
+    exactly once, never give one workgroup more than ceil(T/G) + a whole item's slack, and cut an
+    item only inside the tail."""
+    monkeypatch.delenv("WINO_SK_GRID", raising=False)
+    monkeypatch.delenv("WINO_SK_MIN_ITERS", raising=False)
+    G, rounds, tail_iters, nch = _plan(pkg, N, H, W, C, K, cus)
+    tiles = N * ((H + 1) // 2) * ((W + 1) // 2)
+    items = -(-tiles // 64) * (K // 64)
+    assert nch == C // 8 and G >= 1 and rounds == items // G
+    assert tail_iters == (items % G) * nch
+    assert G <= max(cus, 1) or G == items          # at most one workgroup per CU, or one item each
+    seen = np.zeros((items, nch), np.int32)
+    loads = []
+    for l in range(G):
+        mine = 0
+        t0, t1 = l * tail_iters // G, (l + 1) * tail_iters // G     # the kernel's sk_start()
+        for t in range(t0, t1):
+            seen[rounds * G + t // nch, t % nch] += 1
+        mine += t1 - t0
+        for r in range(rounds):
+            seen[r * G + l, :] += 1
+            mine += nch
+        loads.append(mine)
+    assert (seen == 1).all()
+    assert max(loads) - min(loads) <= 1
+    # the two headline facts of DESIGN.md section 3.1
+    if (N, H, C, K, cus) == (128, 14, 256, 256, 256):
+        assert (G, rounds, tail_iters) == (256, 1, 136 * 32) and max(loads) == 49
+    if (N, H, C, K, cus) == (128, 14, 128, 128, 256):
+        assert (G, rounds, tail_iters) == (196, 1, 0)
+
+
+def test_launch_plan_rejects_bad_shapes(pkg):
+    L = pkg.lib()
+    g, r, it = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    t = ctypes.c_long()
+    args = (ctypes.byref(g), ctypes.byref(r), ctypes.byref(t), ctypes.byref(it))
+    assert L.wino_conv3x3_plan(1, 14, 14, 12, 64, 256, *args) != 0      # C % 8
+    assert L.wino_conv3x3_plan(1, 14, 14, 16, 32, 256, *args) != 0      # K % 64
+    assert L.wino_conv3x3_plan(1, 0, 14, 16, 64, 256, *args) != 0       # empty feature map
+    assert L.wino_conv3x3_plan(1 << 20, 56, 56, 64, 64, 256, *args) != 0  # beyond 4 GiB
