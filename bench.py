@@ -43,6 +43,8 @@ LAYERS = {
     "conv3x3_64_56x56": ("3x3", 64, 64, True),
     "conv3x3_128_28x28": ("3x3", 128, 128, True),
     "conv3x3_512_7x7": ("3x3", 512, 512, True),
+    # the reference's own unfused F(4x4,3x3) arithmetic on its weight_winograd file
+    "conv3x3_256_f4compat": ("3x3f4", 256, 256, True),
 }
 FEATURE_MAP = {"conv3x3_64_56x56": 56, "conv3x3_128_28x28": 28, "conv3x3_512_7x7": 7}   # default 14
 BATCH = 128
@@ -51,13 +53,15 @@ BATCH = 128
 def algorithmic_flops(kind: str, N: int, C: int, K: int, H: int = 14) -> float:
     if kind == "block":   # C = outer width (1024), K = bottleneck width (256): 436.7 MFLOP / image
         return 2.0 * N * 14 * 14 * (C * K + K * K * 9 + K * C)
-    return 2.0 * N * H * H * K * C * (9 if kind == "3x3" else 1)
+    return 2.0 * N * H * H * K * C * (9 if kind in ("3x3", "3x3f4") else 1)
 
 
 def executed_mfma_flops(kind: str, N: int, C: int, K: int, H: int = 14) -> float:
     """FLOPs the MFMA pipes execute: F(2x2,3x3) = 16 points x (N*(H/2)^2 tiles) x C x K x 2."""
     if kind == "block":
         return 2.0 * N * 14 * 14 * 2 * C * K + 2.0 * 16 * N * 49 * K * K
+    if kind == "3x3f4":   # 36 points x 16 tiles per image
+        return 2.0 * 36 * N * 16 * C * K
     return 2.0 * 16 * N * ((H + 1) // 2) ** 2 * C * K if kind == "3x3" else algorithmic_flops(kind, N, C, K)
 
 
@@ -208,6 +212,16 @@ def main():
         U = pkg.filter_transform_f2(rnd(K, C, 3, 3))       # offline, outside the timed region
         out = torch.empty((N, H + 2, H + 2, K), device=dev)
         step = lambda: pkg.conv3x3_bn_relu(x, U, bias_v, scale_v, relu=relu, out=out)
+    elif kind == "3x3f4":
+        x = rnd(N, 16, 16, C)
+        u36 = rnd(36, C, K)
+        out = torch.empty((N, 16, 16, K), device=dev)
+        nbytes = pkg.lib().wino_conv3x3_f4_workspace_bytes(N, C, K)
+        ws = torch.empty(nbytes // 4, device=dev)
+        L = pkg.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        step = lambda: L.wino_conv3x3_f4_bn_relu(x.data_ptr(), u36.data_ptr(), bias_v.data_ptr(), scale_v.data_ptr(),
+                                                 out.data_ptr(), N, C, K, 1, ws.data_ptr(), nbytes, stream)
     elif kind == "block":
         x = rnd(N, 14, 14, C)
         w1, w3 = rnd(C, K, scale=4.0 / C ** 0.5), rnd(K, C, scale=4.0 / K ** 0.5)
@@ -281,6 +295,7 @@ def main():
                                f"ResNet bottleneck 1x1 {C}->{K}, 3x3 {K}->{K}, 1x1 {K}->{C} + skip (BN+ReLU fused), "
                                f"14x14, N={N} per GPU, fp32",
                    "algorithm": {"3x3": "fused Winograd F(2x2,3x3), one HIP launch",
+                                 "3x3f4": "unfused Winograd F(4x4,3x3) compatibility path: transform, batched MFMA GEMM, inverse (4 launches)",
                                  "1x1": "fp32 MFMA GEMM, one HIP launch",
                                  "block": "3 HIP launches: MFMA GEMM, fused Winograd F(2x2,3x3), MFMA GEMM+skip"}[kind],
                    "global_batch": N * world, "parallelism": f"batch-split x{world}, no collective"},
@@ -293,7 +308,7 @@ def main():
                      "note": "achieved = algorithmic (direct-conv) FLOPs per launch / mean launch "
                              "duration from HIP events; Winograd executes 2.25x fewer MFMA FLOPs"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "block" and H == 14:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind in ("3x3", "1x1") and H == 14:
         line["cpu_baseline"] = cpu_baseline(kind, C, K, relu, args.cpu_images)
     if world > 1:
         barrier()

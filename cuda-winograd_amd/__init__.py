@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "wino_event_record", "wino_event_elapsed_ms", "wino_filter_f2_elems", "wino_filter_f2_index",
     "wino_filter_transform_f2", "wino_filter_import_f4", "wino_conv3x3_bn_relu", "wino_conv3x3_prepare",
     "wino_conv3x3_bn_relu_hw", "wino_conv3x3_prepare_hw", "wino_conv3x3_direct_hw", "wino_conv3x3_plan",
+    "wino_conv3x3_f4_bn_relu", "wino_conv3x3_f4_workspace_bytes",
     "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_bn_ex", "wino_conv1x1_direct",
     "wino_residual_block", "wino_residual_block_workspace_bytes", "wino_driver_set_batch",
     "wino_driver_set_gpus", "wino_driver_set_quiet", "wino_driver_get_batch",
@@ -77,6 +78,9 @@ def lib() -> ctypes.CDLL:
     L.wino_conv3x3_prepare.argtypes = [c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_bn_relu_hw.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_prepare_hw.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p]
+    L.wino_conv3x3_f4_workspace_bytes.restype = c_size_t
+    L.wino_conv3x3_f4_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.wino_conv3x3_f4_bn_relu.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, fp, c_size_t, c_void_p]
     L.wino_conv3x3_plan.argtypes = [c_int] * 6 + [POINTER(c_int), POINTER(c_int), POINTER(c_long), POINTER(c_int)]
     L.wino_conv3x3_direct_hw.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_direct.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_void_p]
@@ -167,6 +171,26 @@ def conv3x3_bn_relu(inp: torch.Tensor, U: torch.Tensor, bn_bias: torch.Tensor,
         _check(lib().wino_conv3x3_bn_relu_hw(x.data_ptr(), U.data_ptr(), b.data_ptr(), s.data_ptr(),
                                              out.data_ptr(), N, Hp - 2, Wp - 2, C, K, int(relu), _stream()),
                "wino_conv3x3_bn_relu_hw")
+    return out
+
+
+def conv3x3_f4_bn_relu(inp: torch.Tensor, u36: torch.Tensor, bn_bias: torch.Tensor, bn_scale: torch.Tensor,
+                       relu: bool = True) -> torch.Tensor:
+    """F(4x4,3x3) compatibility path: the reference's three stages on its own weight_winograd tensor
+    u36 [36][C][K], consumed as is.  inp [N][16][16][C] -> out [N][16][16][K]."""
+    x, u = _dev(inp, "inp"), _dev(u36, "u36")
+    b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
+    if x.dim() != 4 or tuple(x.shape[1:3]) != (16, 16) or u.dim() != 3 or u.shape[0] != 36:
+        raise WinoError("inp must be [N][16][16][C], u36 [36][C][K]")
+    N, C, K = int(x.shape[0]), int(x.shape[3]), int(u.shape[2])
+    if int(u.shape[1]) != C or b.numel() != K or s.numel() != K:
+        raise WinoError("u36 / bn vectors do not match C, K")
+    out = torch.empty((N, 16, 16, K), dtype=torch.float32, device=x.device)
+    nbytes = lib().wino_conv3x3_f4_workspace_bytes(N, C, K)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _check(lib().wino_conv3x3_f4_bn_relu(x.data_ptr(), u.data_ptr(), b.data_ptr(), s.data_ptr(), out.data_ptr(),
+                                         N, C, K, int(relu), ws.data_ptr(), nbytes, _stream()),
+           "wino_conv3x3_f4_bn_relu")
     return out
 
 

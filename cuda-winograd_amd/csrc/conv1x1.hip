@@ -55,7 +55,7 @@ using namespace wino;
 template <int BK, int NW>
 static int launch_1x1(const float* A, const float* B, const float* bnBias, const float* bnScale,
                       const float* R, float* C, long M, int Cin, int Kout, int flags, int nMB,
-                      hipStream_t s) {
+                      hipStream_t s, int batch = 1, long batchA = 0, long batchB = 0, long batchC = 0) {
   using G = Cfg<BK, NW>;
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
@@ -66,10 +66,27 @@ static int launch_1x1(const float* A, const float* B, const float* bnBias, const
     attr_done.fetch_or(1ull << (dev & 63));
   }
   const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
-  hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW>), dim3(grid), dim3(G::NT), G::LDS_BYTES, s, A, B,
-                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB);
+  hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW>), dim3(grid, batch), dim3(G::NT), G::LDS_BYTES, s, A, B,
+                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC);
   return launch_status("conv1x1_bn_kernel");
 }
+
+namespace wino {
+// Batched plain GEMM C_b = A_b . B_b (no BN) on the 1x1 kernel: used by the F(4x4) compatibility path.
+int gemm_batched(const float* A, const float* B, float* C, long M, int Cin, int Kout, int batch,
+                 long batchA, long batchB, long batchC, hipStream_t s) {
+  if ((Cin % 32) != 0 || (Kout % 64) != 0 || M < 1 || batch < 1 || batch > 65535) {
+    set_error("unsupported batched GEMM shape");
+    return WINO_E_SHAPE;
+  }
+  const int nMB = (int)((M + BM - 1) / BM);
+  if (Kout <= 128 || Cin <= 128)
+    return launch_1x1<32, 4>(A, B, nullptr, nullptr, nullptr, C, M, Cin, Kout, gemm1x1::WINO_INTERNAL_NO_BN, nMB, s,
+                             batch, batchA, batchB, batchC);
+  return launch_1x1<32, 8>(A, B, nullptr, nullptr, nullptr, C, M, Cin, Kout, gemm1x1::WINO_INTERNAL_NO_BN, nMB, s,
+                           batch, batchA, batchB, batchC);
+}
+}  // namespace wino
 
 extern "C" {
 

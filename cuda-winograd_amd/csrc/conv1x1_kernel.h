@@ -10,6 +10,7 @@ namespace wino {
 namespace gemm1x1 {
 
 constexpr int BM = 112;
+constexpr int WINO_INTERNAL_NO_BN = 1 << 16;   // not part of the public flag set
 constexpr int RB = BM / 16;  // 7 row blocks
 
 __device__ __forceinline__ void wait_lds1(int n) {
@@ -80,8 +81,13 @@ __global__ void __launch_bounds__(64 * NW, 2)
 conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                   const float* __restrict__ bnBias, const float* __restrict__ bnScale,
                   const float* __restrict__ R, float* __restrict__ Cout, long M, int Cin, int Kout,
-                  int flags, int nMB) {
+                  int flags, int nMB, long batchA, long batchB, long batchC) {
   using G = Cfg<BK, NW>;
+  // batched GEMMs (the 36 Winograd points of the F(4x4) compatibility path): blockIdx.y selects
+  // the problem, the three operands advance by their batch strides (in floats)
+  A += (size_t)blockIdx.y * batchA;
+  B += (size_t)blockIdx.y * batchB;
+  Cout += (size_t)blockIdx.y * batchC;
   constexpr int BN = G::BN;
   const bool relu = flags & WINO_RELU, a_padded = flags & WINO_A_PADDED;
   const bool c_padded = flags & WINO_C_PADDED, add_res = flags & WINO_ADD_RESIDUAL;
@@ -224,7 +230,8 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   float* img = (float*)smem;
   {
     const int col = n0 + 16 * w + r16;
-    const float sc = bnScale[col], bi = bnBias[col];
+    const bool raw = flags & WINO_INTERNAL_NO_BN;   // plain GEMM: no scale / bias vectors at all
+    const float sc = raw ? 1.f : bnScale[col], bi = raw ? 0.f : bnBias[col];
     float* wr = img + (4 * h) * BN + ((16 * w + r16) ^ (h << 4));
 #pragma unroll
     for (int rb = 0; rb < RB; rb++) {

@@ -1,0 +1,160 @@
+// F(4x4,3x3) compatibility path: the reference's own arithmetic --
+// its three launches kernel_*_winograd_BtdB -> kernel_*_OuterProduct_* -> kernel_*_winograd_AtIA
+// (Kernel128_winograd.cu:28-213, Kernel256_winograd.cu:27-218) -- on the reference's own
+// pre-transformed weight file weight_winograd_C_K.bin ([36][C][K], data_generator.py:63-78), consumed
+// AS IS (no re-transformation).  Unfused on purpose: V and M live in a caller-provided workspace like
+// the reference's t_input / ip buffers (:117-119,212), so every stage can be diffed against the
+// oracle's stage-by-stage restatement.  The product path is the fused F(2x2,3x3) kernel; this one
+// exists for byte-level weight compatibility and for numerics that follow the reference's order of
+// operations (6x6 transforms in fp32, 16 tiles of 4x4 outputs per image, clipped to 14x14).
+//
+//   V [36][N*16][C]  = B^T d B per 6x6 patch (tile (tx,ty) = rows 4tx.., cols 4ty..; reads past
+//                      row/col 15 see zeros, which only feed outputs that the clip drops)
+//   M [36][N*16][K]  = V_e . U_e for the 36 points: one batched launch of the 1x1 MFMA GEMM kernel
+//   out              = relu(scale * A^T M A + bias), rows/cols 1..14 of the padded image, ring 0
+#include "wino_common.h"
+
+namespace wino {
+int gemm_batched(const float* A, const float* B, float* C, long M, int Cin, int Kout, int batch,
+                 long batchA, long batchB, long batchC, hipStream_t s);   // conv1x1.hip
+
+namespace {
+
+// B^T of F(4x4,3x3) applied to six values (rows of BT_F4 in oracle/oracle.py; Kernel128_winograd.cu:42-73)
+__device__ __forceinline__ void bt6(const float d[6], float o[6]) {
+  o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  o[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+  o[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+  o[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+  o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+  o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+// A^T of F(4x4,3x3) applied to six values (AT_F4; Kernel128_winograd.cu:133-153)
+__device__ __forceinline__ void at6(const float m[6], float o[4]) {
+  o[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+  o[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+  o[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+  o[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+
+// thread -> (tile g = n*16 + tx*4 + ty, channel c); adjacent threads take adjacent channels
+__global__ void f4_input_transform_kernel(const float* __restrict__ in, float* __restrict__ V, int N, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long T = (long)N * 16;
+  if (idx >= T * C) return;
+  const int c = (int)(idx % C);
+  const long g = idx / C;
+  const int n = (int)(g >> 4), tx = (int)(g >> 2) & 3, ty = (int)g & 3;
+  float d[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int row = 4 * tx + i, col = 4 * ty + j;
+      d[i][j] = (row < WINO_HW && col < WINO_HW) ? in[((size_t)(n * WINO_HW + row) * WINO_HW + col) * C + c] : 0.f;
+    }
+  float t[6][6];   // B^T d: transform the rows index
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float colv[6], o[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) colv[i] = d[i][j];
+    bt6(colv, o);
+#pragma unroll
+    for (int i = 0; i < 6; i++) t[i][j] = o[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {   // (B^T d) B: transform the columns index
+    float o[6];
+    bt6(t[i], o);
+#pragma unroll
+    for (int l = 0; l < 6; l++) V[((size_t)(i * 6 + l) * T + g) * C + c] = o[l];
+  }
+}
+
+// thread -> (tile g, out-channel k): A^T m A, BN, ReLU, clip to rows/cols 1..14
+__global__ void f4_output_transform_kernel(const float* __restrict__ M, const float* __restrict__ bnBias,
+                                           const float* __restrict__ bnScale, float* __restrict__ out,
+                                           int N, int K, int relu) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long T = (long)N * 16;
+  if (idx >= T * K) return;
+  const int k = (int)(idx % K);
+  const long g = idx / K;
+  const int n = (int)(g >> 4), tx = (int)(g >> 2) & 3, ty = (int)g & 3;
+  float t[4][6];   // A^T m
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float colv[6], o[4];
+#pragma unroll
+    for (int i = 0; i < 6; i++) colv[i] = M[((size_t)(i * 6 + j) * T + g) * K + k];
+    at6(colv, o);
+#pragma unroll
+    for (int a = 0; a < 4; a++) t[a][j] = o[a];
+  }
+  const float sc = bnScale[k], bi = bnBias[k];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    float o[4];
+    at6(t[a], o);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int row = 4 * tx + 1 + a, col = 4 * ty + 1 + b;
+      if (row <= WINO_PQ && col <= WINO_PQ) {   // the reference's clip (Kernel128_winograd.cu:155,171,177)
+        float y = sc * o[b] + bi;
+        if (relu) y = fmaxf(y, 0.f);
+        out[((size_t)(n * WINO_HW + row) * WINO_HW + col) * K + k] = y;
+      }
+    }
+  }
+}
+
+// the zero ring of the padded output: thread -> (n, ring pixel q of 60, k)
+__global__ void f4_ring_kernel(float* __restrict__ out, int N, int K) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * 60 * K) return;
+  const int k = (int)(idx % K);
+  const long p = idx / K;
+  const int n = (int)(p / 60), q = (int)(p % 60);
+  const int y = q < 16 ? 0 : q < 32 ? WINO_HW - 1 : q < 46 ? q - 31 : q - 45;
+  const int x = q < 16 ? q : q < 32 ? q - 16 : q < 46 ? 0 : WINO_HW - 1;
+  out[((size_t)(n * WINO_HW + y) * WINO_HW + x) * K + k] = 0.f;
+}
+
+}  // namespace
+}  // namespace wino
+
+using namespace wino;
+
+extern "C" {
+
+size_t wino_conv3x3_f4_workspace_bytes(int N, int C, int K) {
+  return (size_t)36 * N * 16 * ((size_t)C + K) * sizeof(float);
+}
+
+int wino_conv3x3_f4_bn_relu(const float* in, const float* u36, const float* bnBias, const float* bnScale,
+                            float* out, int N, int C, int K, int relu, void* workspace,
+                            size_t workspace_bytes, wino_stream_t s) {
+  if (!in || !u36 || !bnBias || !bnScale || !out || !workspace) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if (N < 1 || C <= 0 || K <= 0 || (C % 32) != 0 || (K % 64) != 0) {
+    set_error("unsupported F(4x4) shape N=%d C=%d K=%d (need C %% 32 == 0, K %% 64 == 0)", N, C, K);
+    return WINO_E_SHAPE;
+  }
+  if (workspace_bytes < wino_conv3x3_f4_workspace_bytes(N, C, K)) {
+    set_error("workspace too small: need %zu bytes", wino_conv3x3_f4_workspace_bytes(N, C, K));
+    return WINO_E_ARG;
+  }
+  const long T = (long)N * 16;
+  float* V = (float*)workspace;
+  float* M = V + (size_t)36 * T * C;
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(f4_input_transform_kernel, dim3((unsigned)((T * C + 255) / 256)), dim3(256), 0, st, in, V, N, C);
+  if (int rc = launch_status("f4_input_transform_kernel")) return rc;
+  if (int rc = gemm_batched(V, u36, M, T, C, K, 36, T * C, (long)C * K, T * K, st)) return rc;
+  hipLaunchKernelGGL(f4_ring_kernel, dim3((unsigned)(((long)N * 60 * K + 255) / 256)), dim3(256), 0, st, out, N, K);
+  hipLaunchKernelGGL(f4_output_transform_kernel, dim3((unsigned)((T * K + 255) / 256)), dim3(256), 0, st, M,
+                     bnBias, bnScale, out, N, K, relu);
+  return launch_status("f4_output_transform_kernel");
+}
+
+}  // extern "C"

@@ -130,6 +130,19 @@ int wino_conv3x3_prepare_hw(int N, int H, int W, int C, int K, wino_stream_t s);
 int wino_conv3x3_plan(int N, int H, int W, int C, int K, int cus, int* grid, int* rounds, long* tail_iters,
                       int* iters_per_item);
 
+/* ---- F(4x4,3x3) compatibility path ------------------------------
+ * The reference's own three-stage arithmetic on its own pre-transformed weight file, consumed as is:
+ * u36 = weight_winograd_C_K.bin, [36][C][K] (data_generator.py:63-78).  V = B^T d B (6x6 patches, 16
+ * tiles per image), M_e = V_e . U_e for the 36 points (one batched MFMA GEMM launch), out = relu(scale *
+ * A^T M A + bias) clipped to 14x14 (Kernel128_winograd.cu:28-213).  V and M live in `workspace`
+ * (wino_conv3x3_f4_workspace_bytes), like the reference's t_input / ip buffers.  Same in / out layout as
+ * wino_conv3x3_bn_relu.  Unfused and HBM-bound by design; the product path is the fused F(2x2) kernel.
+ * Constraints: C % 32 == 0, K % 64 == 0. */
+size_t wino_conv3x3_f4_workspace_bytes(int N, int C, int K);
+int wino_conv3x3_f4_bn_relu(const float* in, const float* u36, const float* bnBias, const float* bnScale,
+                            float* out, int N, int C, int K, int relu, void* workspace,
+                            size_t workspace_bytes, wino_stream_t s);
+
 /* Independent comparator: direct (non-Winograd) 3x3 conv + BN + ReLU on the GPU,
  * w_kcrs [K][C][3][3]; same in/out layout as above.  Slow by design. */
 int wino_conv3x3_direct(const float* in, const float* w_kcrs, const float* bnBias,

@@ -71,6 +71,47 @@ def test_reference_layers_match_golden(C, weights, data_dir, pkg, O, golden_outp
     assert max_err < 1e-4 and cnt < 0.01 * g.size
 
 
+@pytest.mark.parametrize("C", [128, 256])
+def test_f4_compat_path_on_reference_files(C, data_dir, pkg, O, golden_outputs, torch_dev):
+    """the reference's own F(4x4,3x3) arithmetic on its own
+    weight_winograd_C_K.bin, consumed as is.  Against (a) the oracle's stage-by-stage restatement of
+    the reference's three launches (same fp32 recipe: agreement to rounding), (b) the fp64
+    direct-convolution golden output of ./Test 0 / ./Test 1 within the reference's own acceptance,
+    (c) the fused F(2x2) product path; zero ring."""
+    x = load_bin(data_dir, f"input_14_1_{C}.bin").reshape(1, 16, 16, C)
+    s = load_bin(data_dir, f"bnScale_winograd_{C}.bin")
+    b = load_bin(data_dir, f"bnBias_winograd_{C}.bin")
+    u36 = load_bin(data_dir, f"weight_winograd_{C}_{C}.bin").reshape(36, C, C)
+    got = pkg.conv3x3_f4_bn_relu(_t(torch_dev, x), _t(torch_dev, u36), _t(torch_dev, b), _t(torch_dev, s)).cpu().numpy()
+    staged = O.winograd_f4_reference(x, u36, s, b)
+    assert O.rel_error(got, staged) < 2e-5   # two fp32 pipelines, different summation order over C
+    g = golden_outputs[f"kernel_{C}"]
+    assert O.rel_error(got[0, 1:15, 1:15, :], g) < 1e-4          # F(4x4) in fp32: ~1e-5 (report section 5)
+    max_err, cnt = O.output_checker(got[0], g, 14, C, 1)         # the reference's own check
+    assert max_err < 1e-3
+    assert (got[0][_ring()] == 0).all()
+    f2 = pkg.conv3x3_bn_relu(_t(torch_dev, x), pkg.filter_import_f4(_t(torch_dev, u36)), _t(torch_dev, b),
+                             _t(torch_dev, s)).cpu().numpy()
+    assert O.rel_error(got, f2) < 1e-4
+
+
+def test_f4_compat_path_batched(pkg, O, torch_dev):
+    """Batch, several images per row tile of the batched GEMM (M = 16 N not a multiple of 112),
+    C != K, no ReLU: against the fp64 direct convolution with filters transformed the reference's
+    way (G g G^T in fp64, stored fp32)."""
+    rng = np.random.RandomState(91)
+    N, C, K = 13, 64, 128
+    x, w, s, b = _rand_layer(rng, N, C, K)
+    G = O.G_F4
+    u36 = np.einsum('xr,kcrs,ys->xyck', G, w.astype(np.float64), G).reshape(36, C, K).astype(np.float32)
+    for relu in (True, False):
+        got = pkg.conv3x3_f4_bn_relu(_t(torch_dev, x), _t(torch_dev, u36), _t(torch_dev, b), _t(torch_dev, s),
+                                     relu=relu).cpu().numpy()
+        want = O.conv3x3_bn_relu_direct(x, w, s, b, relu=relu)
+        assert O.rel_error(got, want) < 1e-4
+        assert (got[:, _ring(), :] == 0).all()
+
+
 def test_filter_transforms_match_oracle(data_dir, pkg, O, torch_dev):
     """a12: the offline filter transform.  U = G g G^T (fp64 -> fp32) lands where
     wino_filter_f2_index says, for both entry points (raw taps and the reference's F(4x4) file)."""
