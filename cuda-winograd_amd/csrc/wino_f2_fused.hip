@@ -6,24 +6,28 @@
 // with ONE kernel; the Winograd-domain tensors V (input) and M (products) never touch
 // memory.  Design:
 //
-//   workgroup  = 512 threads = 8 waves (2 per SIMD), owns TB=64 tiles x KB=64 out-channels
-//                x all 16 Winograd points; C is streamed in chunks of BC=8 channels.
+//   item       = TB=64 tiles x KB=64 out-channels x all 16 Winograd points; C is streamed in
+//                chunks of BC=8 channels ("chunk iterations").  The launch is balanced by
+//                iterations: whole-item rounds + a stream-K tail (wino_f2_fused_kernel.h).
+//   workgroup  = 512 threads = 8 waves (2 per SIMD), all 160 KB of the CU's LDS.
 //   wave (wt,wk) = 16 tiles x 32 out-channels x 16 points
 //                = 32 accumulator tiles of v_mfma_f32_16x16x4_f32 (128 acc VGPRs).
 //   per chunk  : LDS-DMA (buffer_load_dwordx4 ... lds) stages
 //                  raw[64 tiles][16 px][8 c]   (the 4x4 input patches, 32 KB, 2 stages)
 //                  U  [16 pts][64 k][8 c]      (pre-packed filter chunk, 32 KB, 3 stages)
-//                two chunks ahead of the MFMAs (all 160 KB of the CU's LDS).
+//                two iterations ahead of the MFMAs, continuously across items.
 //   A operand  : each lane reads its tile's 4x4 patch for 2 channels (16 x ds_read_b64),
-//                applies B^T d B in registers (32 VALU adds per channel) -> V[16 pts];
+//                applies B^T d B in registers (32 packed adds) -> V[16 pts];
 //                no cross-lane traffic is needed because the MFMA A-fragment wants
 //                exactly "one tile row, one channel" per lane.
 //   B operand  : ds_read_b64 of the packed filter chunk.
 //   epilogue   : the 16 accumulators of one (tile, k) sit in the SAME lane/register slot
 //                of 16 different MFMA tiles, so A^T m A is 24 in-lane adds; then
-//                scale*y+bias, ReLU; the tile is transposed through LDS and leaves as whole
-//                256-byte pixel rows of the padded NHWC output, plus the zero ring.
-// Small batches (the reference's N = 1) take wino_f2_small_kernel.h instead.
+//                scale*y+bias, ReLU; each wave's tiles go through its own 8 KB of LDS and leave as
+//                whole 128-byte runs of the padded NHWC output; the zero ring is written once per
+//                launch by a flat ring pass.
+// Small batches (the reference's N = 1) take wino_f2_small_kernel.h instead; feature maps other
+// than 14x14 run the same kernel with the geometry in its arguments (GEN = true).
 //
 // LDS bank-conflict avoidance is done by XOR-permuting 16-byte units, applied on the DMA
 // *source* address for the raw patches (the LDS destination of an LDS-DMA is lane-linear)
