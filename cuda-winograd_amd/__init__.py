@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "wino_event_record", "wino_event_elapsed_ms", "wino_filter_f2_elems", "wino_filter_f2_index",
     "wino_filter_transform_f2", "wino_filter_import_f4", "wino_conv3x3_bn_relu", "wino_conv3x3_prepare",
     "wino_conv3x3_bn_relu_hw", "wino_conv3x3_prepare_hw", "wino_conv3x3_direct_hw", "wino_conv3x3_plan",
+    "wino_conv1x1_prepare",
     "wino_conv3x3_f4_bn_relu", "wino_conv3x3_f4_workspace_bytes",
     "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_bn_ex", "wino_conv1x1_direct",
     "wino_residual_block", "wino_residual_block_workspace_bytes", "wino_driver_set_batch",
@@ -76,6 +77,7 @@ def lib() -> ctypes.CDLL:
     L.wino_filter_import_f4.argtypes = [fp, fp, c_int, c_int, c_void_p]
     L.wino_conv3x3_bn_relu.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_prepare.argtypes = [c_int, c_int, c_int, c_void_p]
+    L.wino_conv1x1_prepare.argtypes = [c_long, c_int, c_int, c_void_p]
     L.wino_conv3x3_bn_relu_hw.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_prepare_hw.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_f4_workspace_bytes.restype = c_size_t
@@ -232,6 +234,11 @@ def conv1x1_bn(A: torch.Tensor, B: torch.Tensor, bn_bias: torch.Tensor, bn_scale
 
 
 RELU, A_PADDED, C_PADDED, ADD_RESIDUAL = 1, 2, 4, 8  # WINO_* flag bits of wino_conv1x1_bn_ex
+
+
+def conv1x1_prepare(M: int, Cin: int, Kout: int) -> None:
+    """Allocate the 1x1 layer's stream-K scratch for the current stream (before graph capture)."""
+    _check(lib().wino_conv1x1_prepare(int(M), int(Cin), int(Kout), _stream()), "wino_conv1x1_prepare")
 
 
 def conv1x1_bn_ex(A, B, bn_bias, bn_scale, flags: int, residual=None, out=None) -> torch.Tensor:

@@ -52,10 +52,46 @@ __global__ void conv1x1_direct_kernel(const float* __restrict__ A, const float* 
 
 using namespace wino;
 
+// Stream-K grid for `tiles` output tiles of nk k-steps on `cus` CUs, or 0 for the plain
+// one-tile-per-workgroup launch.  A launch costs ceil(tiles / cus) workgroup-times whatever the
+// occupancy (see conv1x1_kernel.h), so the plain form wastes rounds * cus / tiles - 1; stream-K
+// runs G = rounds * cus equal ranges instead and pays one slab round trip per range.  Taken when
+// the waste is above 6 % and a range keeps at least SK1_AUTO_STEPS k-steps (the hand-over sits at
+// the end of every range, on the launch's critical path: measured at N = 128, 1024->256 with 28
+// steps per range 118 -> 111 us, 512->128 with 14 steps per range 33 -> 35 us).
+// Developer overrides, read per call so that tests can sweep the decomposition: WINO_1X1_SK=0 / 1
+// forces the plain / stream-K form (1: whenever a legal grid exists), WINO_1X1_SK_GRID=G sets the
+// number of ranges (rounded down to a multiple of 8, at most one range per k-step).
+constexpr int SK1_MIN_STEPS = 8, SK1_AUTO_STEPS = 24;
+static int sk1_grid(long long tiles, int nk, int cus) {
+  const char* f_env = getenv("WINO_1X1_SK");
+  const char* g_env = getenv("WINO_1X1_SK_GRID");
+  const int force = f_env && *f_env ? atoi(f_env) : -1;
+  if (force == 0 || cus < 8 || tiles < 1) return 0;
+  const long long U = tiles * nk;
+  if (g_env && *g_env) {
+    long long G = atoll(g_env);
+    if (G > U) G = U;
+    if (G > (1 << 20)) G = 1 << 20;
+    G &= ~7ll;
+    return G >= 8 ? (int)G : 0;
+  }
+  const long long rounds = (tiles + cus - 1) / cus;
+  long long G = rounds * cus;
+  if (G > U / SK1_MIN_STEPS) G = U / SK1_MIN_STEPS;
+  G &= ~7ll;                                   // whole XCD groups
+  if (G < 8 || G <= tiles) return 0;           // nothing to split
+  if (G > (1 << 20)) return 0;
+  if (force == 1) return (int)G;
+  const double waste = (double)(rounds * cus) / (double)tiles - 1.0;
+  return waste > 0.06 && tiles >= cus && U / G >= SK1_AUTO_STEPS ? (int)G : 0;
+}
+
 template <int BK, int NW>
 static int launch_1x1(const float* A, const float* B, const float* bnBias, const float* bnScale,
                       const float* R, float* C, long M, int Cin, int Kout, int flags, int nMB,
-                      hipStream_t s, int batch = 1, long batchA = 0, long batchB = 0, long batchC = 0) {
+                      hipStream_t s, int batch = 1, long batchA = 0, long batchB = 0, long batchC = 0,
+                      bool prepare_only = false) {
   using G = Cfg<BK, NW>;
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
@@ -63,11 +99,26 @@ static int launch_1x1(const float* A, const float* B, const float* bnBias, const
   if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
     WINO_HIP(hipFuncSetAttribute((const void*)(conv1x1_bn_kernel<BK, NW>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    WINO_HIP(hipFuncSetAttribute((const void*)(conv1x1_bn_kernel<BK, NW, 0, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_done.fetch_or(1ull << (dev & 63));
   }
+  int cus = 0;
+  if (int rc = device_cus(dev, &cus)) return rc;
+  const long long tiles = (long long)nMB * (Kout / G::BN);
+  const int Gsk = batch == 1 ? sk1_grid(tiles, Cin / BK, cus) : 0;
+  if (Gsk) {
+    SkArgs sk{nullptr, nullptr};
+    if (int rc = sk_scratch(dev, s, (size_t)2 * Gsk * NW * RB * 1024, (size_t)tiles, &sk.slabs, &sk.tickets)) return rc;
+    if (prepare_only) return WINO_OK;
+    hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW, 0, true>), dim3(Gsk), dim3(G::NT), G::LDS_BYTES, s, A, B,
+                       bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, 0L, 0L, 0L, sk);
+    return launch_status("conv1x1_bn_kernel (stream-K)");
+  }
+  if (prepare_only) return WINO_OK;
   const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
   hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW>), dim3(grid, batch), dim3(G::NT), G::LDS_BYTES, s, A, B,
-                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC);
+                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC, SkArgs{nullptr, nullptr});
   return launch_status("conv1x1_bn_kernel");
 }
 
@@ -117,6 +168,22 @@ int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, cons
   if (Kout <= 128 || Cin <= 128)
     return launch_1x1<32, 4>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s);
   return launch_1x1<32, 8>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s);
+}
+
+// Allocates the stream-K scratch this shape's launches on stream `s` will use (nothing for shapes
+// that take the plain form): call it before capturing wino_conv1x1_bn(_ex) into a HIP graph.
+int wino_conv1x1_prepare(long M, int Cin, int Kout, wino_stream_t s) {
+  if (M < 1 || Cin <= 0 || Kout <= 0 || (Cin % 32) != 0 || (Kout % 64) != 0) {
+    set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% 64 == 0)",
+              M, Cin, Kout);
+    return WINO_E_SHAPE;
+  }
+  const long nMBl = (M + BM - 1) / BM;
+  if (nMBl > (1L << 24)) { set_error("M too large"); return WINO_E_SHAPE; }
+  const int nMB = (int)nMBl;
+  if (Kout <= 128 || Cin <= 128)
+    return launch_1x1<32, 4>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, Cin, Kout, 0, nMB, (hipStream_t)s, 1, 0, 0, 0, true);
+  return launch_1x1<32, 8>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, Cin, Kout, 0, nMB, (hipStream_t)s, 1, 0, 0, 0, true);
 }
 
 int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const float* bnScale,

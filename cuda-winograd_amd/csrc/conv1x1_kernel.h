@@ -1,6 +1,16 @@
 // The 1x1-conv GEMM kernel as a header, so that the library (conv1x1.hip) and the ablation tool
 // (tools/ablate_1x1.hip) compile the same source.  ABLATE (0 = product): 1 skip the A LDS-DMA,
 // 2 skip the B LDS-DMA, 4 skip the MFMAs, 8 skip the per-stage wait+barrier, 512 skip the stores.
+//
+// SK = true is the stream-K launch form.  A workgroup's duration does not depend on whether it
+// shares its CU (measured: 384, 448 and 512 workgroups of the 1024->256 layer all take 116 us, every
+// further 256 add 57 us), so a launch costs ceil(tiles / CUs) workgroup-times and the reference's
+// 448-tile layers pay for 512.  Stream-K cuts the tiles x k-steps space into G = CUs * ceil(tiles /
+// CUs) equal contiguous ranges instead; a range is at most two segments (the tail of one tile, the
+// head of the next).  A segment that is not a whole tile stores its raw accumulators as a
+// write-through slab and the workgroup draws one ticket on the tile; whoever draws the tile's last
+// ticket adds all of its segments' slabs in k order (bitwise reproducible) and runs the epilogue.
+// Nobody waits for anybody.  Same slab / ticket rules as the fused 3x3 kernel (wino_f2_fused_kernel.h).
 #pragma once
 #include "wino_common.h"
 
@@ -76,12 +86,19 @@ struct Cfg {
   }
 };
 
-template <int BK, int NW, int ABLATE = 0>
+// scratch of the stream-K form (library-owned, per stream): 2 slab slots of NW*RB KiB per
+// workgroup, one ticket counter per tile (zero between launches)
+struct SkArgs {
+  float* slabs;
+  unsigned* tickets;
+};
+
+template <int BK, int NW, int ABLATE = 0, bool SK = false>
 __global__ void __launch_bounds__(64 * NW, 2)
 conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                   const float* __restrict__ bnBias, const float* __restrict__ bnScale,
                   const float* __restrict__ R, float* __restrict__ Cout, long M, int Cin, int Kout,
-                  int flags, int nMB, long batchA, long batchB, long batchC) {
+                  int flags, int nMB, long batchA, long batchB, long batchC, SkArgs sk = SkArgs{nullptr, nullptr}) {
   using G = Cfg<BK, NW>;
   // batched GEMMs (the 36 Winograd points of the F(4x4) compatibility path): blockIdx.y selects
   // the problem, the three operands advance by their batch strides (in floats)
@@ -92,12 +109,11 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   const bool relu = flags & WINO_RELU, a_padded = flags & WINO_A_PADDED;
   const bool c_padded = flags & WINO_C_PADDED, add_res = flags & WINO_ADD_RESIDUAL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // blocks that share a row tile (same A rows) are adjacent in `slot` on one XCD
   const int NBLK = Kout / BN;
   const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int nb = slot % NBLK;
-  const int mb = (slot / NBLK) * 8 + xcd;
+  const int nk = Cin / BK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (c_padded && !(ABLATE & 512)) {
     // ring pass: the padded output's zero ring (the 3x3 layer's padding) as a flat list of
     // 16-byte units -- M/196 images x 60 ring pixels x Kout/4 units -- split over the grid
@@ -114,12 +130,41 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       *(f32x4*)(Cout + ((size_t)(n * WINO_HW + y) * WINO_HW + x) * Kout + unit * 4) = zero4;
     }
   }
-  if (mb >= nMB) return;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The work of this workgroup: [u, uend) in the space tile * nk + k-step, tile = mb * NBLK + nb
+  // (the NBLK tiles that share A rows are adjacent).
+  //   plain form: one whole tile; blocks that share a row tile are adjacent in `slot` on one XCD
+  //   stream-K  : logical workgroup lg = (bid % 8) * (G / 8) + bid / 8, so that an XCD's
+  //               workgroups walk a contiguous run of tiles (G is a multiple of 8)
+  const int Gsk = (int)gridDim.x;
+  const long long Usk = (long long)nMB * NBLK * nk;
+  auto sk_u0 = [&](int g) -> long long { return Usk * g / Gsk; };
+  int lg = 0;
+  long long u, uend;
+  if (SK) {
+    lg = (bid & 7) * (Gsk >> 3) + (bid >> 3);
+    u = sk_u0(lg);
+    uend = sk_u0(lg + 1);
+  } else {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int mb_plain = (slot / NBLK) * 8 + xcd;
+    if (mb_plain >= nMB) return;
+    u = ((long long)mb_plain * NBLK + slot % NBLK) * nk;
+    uend = u + nk;
+  }
+  const int r16 = lane & 15, h = lane >> 4;
+  bool first_seg = true;
+#pragma unroll 1
+  while (u < uend) {
+  const int tile = (int)(u / nk);
+  const int k0 = (int)(u - (long long)tile * nk);
+  const int len = (int)((uend - u) < (long long)(nk - k0) ? (uend - u) : (long long)(nk - k0));
+  const int nb = tile % NBLK, mb = tile / NBLK;
   const long m0 = (long)mb * BM;
   const int n0 = nb * BN;
+  u += len;
+  // the previous segment's epilogue has read its LDS image before stage 0 is refilled
+  if (SK && !first_seg) __syncthreads();
+  first_seg = false;
 
   // ---- DMA sources --------------------------------------------------------------
   // A piece q covers rows q*RPP .. q*RPP+RPP-1 (RPP = 16 at BK 32... 1 KiB / row bytes);
@@ -157,7 +202,6 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   constexpr int PIECES = G::A_PER_WAVE + G::B_PER_WAVE;
 
   // ---- fragment addresses ---------------------------------------------------------
-  const int r16 = lane & 15, h = lane >> 4;
   // A row rb*16 + r16, sub-chunk s: unit 4s + h, stored at unit' = (4s + h) ^ f(row); f only
   // depends on r16 for both BK (16 rows = a whole number of f periods)
   int a_off[G::S];
@@ -170,9 +214,8 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
 #pragma unroll
   for (int i = 0; i < RB; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = Cin / BK;
 #pragma unroll
-  for (int p = 0; p < PIECES; p++) issue_piece(0, 0, p);
+  for (int p = 0; p < PIECES; p++) issue_piece(0, k0, p);
 
   auto body = [&](auto par, int it) {
     constexpr int PAR = decltype(par)::value;
@@ -180,7 +223,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       wait_vmem_all();
       __syncthreads();
     }
-    const bool more = it + 1 < nk;
+    const bool more = it + 1 < len;   // `it` counts from the segment's first k-step k0
     const char* st = smem + PAR * G::STAGE;
     f32x4 a[G::T];
     float b[G::S][4];
@@ -202,7 +245,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       }
       // this wave's LDS-DMA pieces for the next stage, one per step from step 4 on
       if (t >= 4 && t - 4 < PIECES) {
-        if (more) issue_piece(PAR ^ 1, it + 1, t - 4);
+        if (more) issue_piece(PAR ^ 1, k0 + it + 1, t - 4);
       }
       __builtin_amdgcn_sched_barrier(0);
       wait_lds1(G::wait_count(t));
@@ -215,9 +258,10 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  for (int it = 0; it < nk; it += 2) {
+#pragma unroll 1
+  for (int it = 0; it < len; it += 2) {
     body(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < nk) body(std::integral_constant<int, 1>{}, it + 1);
+    if (it + 1 < len) body(std::integral_constant<int, 1>{}, it + 1);
   }
 
   // ---- epilogue: BN (+residual) (+ReLU).  C/D layout: col = lane&15, row = 4*(lane>>4)+i.
@@ -228,6 +272,66 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   // group h, which keeps the ds_write_b32 of the four row groups on disjoint banks.
   __syncthreads();   // every wave is done with the pipeline stages; no LDS-DMA is in flight
   float* img = (float*)smem;
+  if (SK && !(k0 == 0 && len == nk)) {
+    // Partial segment.  The tile is finished by whoever learns that all of its other segments
+    // have been published: a range's last segment first looks at the tile's counter -- its
+    // neighbours started their share of the tile long ago, so it usually finds them all there and
+    // finalizes straight from its registers, publishing nothing.  Otherwise: publish, draw a
+    // ticket, and unless that was the last one move on.
+    constexpr unsigned SLAB = NW * RB * 1024;
+    const auto rsrc_slab = make_rsrc(sk.slabs, (unsigned)((size_t)2 * Gsk * SLAB));
+    const unsigned slab_voff = (unsigned)((w * RB * 64 + lane) * 16);
+    // the logical workgroups that share this tile, in k order
+    const long long x0 = (long long)tile * nk, x1 = x0 + nk - 1;
+    int gA = lg, gB = lg;
+    while (sk_u0(gA) > x0) gA--;
+    while (gB + 1 < Gsk && sk_u0(gB + 1) <= x1) gB++;
+    const unsigned others = (unsigned)(gB - gA);
+    bool finish = false;
+    if (u >= uend) {   // last segment of the range
+      if (tid == 0)
+        *(volatile unsigned*)smem = __hip_atomic_load(sk.tickets + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      finish = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem) == others;
+    }
+    if (!finish) {
+      // slot 2lg for the segment that continues a tile (head of lg's range), 2lg+1 for the one that starts one
+      const unsigned my_slot = 2u * (unsigned)lg + (k0 == 0 ? 1u : 0u);   // (same value as below)
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++) slab_store16(acc[rb], rsrc_slab, slab_voff + rb * 1024, my_slot * SLAB);
+      wait_vmem_all();   // the write-through stores of every wave have left ...
+      __syncthreads();   // (and everyone has read the counter word above)
+      if (tid == 0)      // ... before the workgroup's ticket
+        *(volatile unsigned*)smem = __hip_atomic_fetch_add(sk.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (__builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem) != others) continue;   // someone else finishes the tile
+    }
+    if (tid == 0)   // self-cleaning counter: the next launch finds 0 again
+      __hip_atomic_store(sk.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The sum runs over the segments in k order, whoever finishes: ((s0 + s1) + s2) + ...  When
+    // this workgroup's own segment is s0 or s1 it stays in the accumulators and the others are
+    // added to it in order (s1 + s0 == s0 + s1 bitwise).  From position 2 on -- ranges much
+    // shorter than a tile -- s0 + s1 has to be formed first: the own segment goes through its slab
+    // like the others (published now if the look at the counter skipped that).
+    const int pos = lg - gA;
+    const unsigned my_slot = 2u * (unsigned)lg + (k0 == 0 ? 1u : 0u);
+    if (pos >= 2 && finish) {
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++) slab_store16(acc[rb], rsrc_slab, slab_voff + rb * 1024, my_slot * SLAB);
+      wait_vmem_all();
+    }
+#pragma unroll 1
+    for (int g = gA; g <= gB; g++) {
+      if (pos < 2 && g == lg) continue;
+      const unsigned slot = 2u * (unsigned)g + (g == gA ? 1u : 0u);
+      f32x4 t[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++) t[rb] = slab_load16(rsrc_slab, slab_voff + rb * 1024, slot * SLAB);
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++) acc[rb] = (pos >= 2 && g == gA) ? t[rb] : acc[rb] + t[rb];
+    }
+    __syncthreads();   // everyone has read the ticket word before the image overwrites it
+  }
   {
     const int col = n0 + 16 * w + r16;
     const bool raw = flags & WINO_INTERNAL_NO_BN;   // plain GEMM: no scale / bias vectors at all
@@ -244,7 +348,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     }
   }
   __syncthreads();
-  if (ABLATE & 512) return;
+  if (ABLATE & 512) continue;
   {
     constexpr int LPR = BN / 4;          // lanes per output row
     constexpr int RPI = 64 / LPR;        // rows per store instruction
@@ -272,6 +376,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       }
     }
   }
+  }   // segments
 }
 
 

@@ -17,6 +17,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Thread-local last-error text behind wino_last_error_string().
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+// Stream-K scratch (wino_runtime.hip): write-through slabs for partial segments and ticket
+// counters, owned by the library, one set per (device, stream) so that launches on different
+// streams never share it; grown on demand (a synchronous hipMalloc: call wino_conv3x3_prepare /
+// wino_conv1x1_prepare first when the launch is going to be captured into a graph).  Launches on
+// one stream run one after the other, so the 3x3 and the 1x1 kernels share a stream's set.
+// Counters are zero at allocation and returned to zero by every launch's last arrivers.
+int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, float** slabs, unsigned** tickets);
+int device_cus(int dev, int* cus);
 
 #define WINO_HIP(call)                                          \
   do {                                                          \

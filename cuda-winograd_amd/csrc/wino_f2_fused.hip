@@ -170,61 +170,14 @@ int wino_filter_import_f4(const float* u36, float* U, int C, int K, wino_stream_
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------
-// Stream-K workspace: write-through slabs for partial segments (2 per logical workgroup) and one
-// ticket counter per item.  Owned by the library, one per (device, stream) so that launches on
-// different streams never share slabs; allocated on first use (a synchronous hipMalloc: call
-// wino_conv3x3_prepare() first when the launch is going to be captured into a graph).  Counters are
-// zeroed at allocation and returned to zero by every launch's last arrivers.
+// Stream-K scratch of this kernel: 2 slabs of SLAB_BYTES per logical workgroup, one ticket counter
+// per (item, wave); the per-(device, stream) set lives in wino_runtime.hip (sk_scratch).
 // ---------------------------------------------------------------------------------
-struct SkWorkspace {
-  int dev;
-  hipStream_t stream;
-  float* slabs;
-  size_t slab_wgs;     // slabs hold 2 * slab_wgs * SLAB_BYTES
-  unsigned* tickets;
-  size_t n_tickets;
-};
-static std::mutex g_ws_mu;
-static std::vector<SkWorkspace> g_ws;
-
-static int sk_cus(int dev, int* cus) {
-  static std::atomic<int> cache[64];
-  int c = dev >= 0 && dev < 64 ? cache[dev].load() : 0;
-  if (!c) {
-    WINO_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
-    if (dev >= 0 && dev < 64) cache[dev].store(c);
-  }
-  *cus = c;
-  return WINO_OK;
-}
+static int sk_cus(int dev, int* cus) { return device_cus(dev, cus); }
 
 static int sk_workspace(int dev, hipStream_t s, int G, size_t items, float** slabs, unsigned** tickets) {
-  items *= 8;   // one ticket counter per (item, wave)
-  std::lock_guard<std::mutex> lock(g_ws_mu);
-  SkWorkspace* ws = nullptr;
-  for (auto& e : g_ws)
-    if (e.dev == dev && e.stream == s) ws = &e;
-  if (!ws) {
-    g_ws.push_back(SkWorkspace{dev, s, nullptr, 0, nullptr, 0});
-    ws = &g_ws.back();
-  }
-  if (ws->slab_wgs < (size_t)G) {
-    if (ws->slabs) { WINO_HIP(hipDeviceSynchronize()); WINO_HIP(hipFree(ws->slabs)); ws->slabs = nullptr; ws->slab_wgs = 0; }
-    const size_t wgs = G < 256 ? 256 : (size_t)G;
-    WINO_HIP(hipMalloc((void**)&ws->slabs, 2 * wgs * SLAB_BYTES));
-    ws->slab_wgs = wgs;
-  }
-  if (ws->n_tickets < items) {
-    if (ws->tickets) { WINO_HIP(hipDeviceSynchronize()); WINO_HIP(hipFree(ws->tickets)); ws->tickets = nullptr; ws->n_tickets = 0; }
-    size_t n = 4096;
-    while (n < items) n *= 2;
-    WINO_HIP(hipMalloc((void**)&ws->tickets, n * sizeof(unsigned)));
-    WINO_HIP(hipMemset(ws->tickets, 0, n * sizeof(unsigned)));
-    ws->n_tickets = n;
-  }
-  *slabs = ws->slabs;
-  *tickets = ws->tickets;
-  return WINO_OK;
+  const size_t wgs = G < 256 ? 256 : (size_t)G;
+  return sk_scratch(dev, s, 2 * wgs * SLAB_BYTES, items * 8, slabs, tickets);
 }
 
 // Launch geometry of the throughput kernel (see the header of wino_f2_fused_kernel.h): G logical

@@ -3,7 +3,10 @@
 // (Test.c:15; Kernel128_winograd.cu:236-286) so that the C host needs no HIP headers.
 #include "wino_common.h"
 
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace wino {
 
@@ -19,6 +22,59 @@ void set_error(const char* fmt, ...) {
 int hip_fail(hipError_t e, const char* what) {
   set_error("%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
   return WINO_E_HIP;
+}
+
+namespace {
+struct SkScratch {
+  int dev;
+  hipStream_t stream;
+  float* slabs;
+  size_t slab_bytes;
+  unsigned* tickets;
+  size_t n_tickets;
+};
+std::mutex g_ws_mu;
+std::vector<SkScratch> g_ws;
+}  // namespace
+
+int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, float** slabs, unsigned** tickets) {
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  SkScratch* ws = nullptr;
+  for (auto& e : g_ws)
+    if (e.dev == dev && e.stream == s) ws = &e;
+  if (!ws) {
+    g_ws.push_back(SkScratch{dev, s, nullptr, 0, nullptr, 0});
+    ws = &g_ws.back();
+  }
+  if (ws->slab_bytes < slab_bytes) {
+    if (ws->slabs) { WINO_HIP(hipDeviceSynchronize()); WINO_HIP(hipFree(ws->slabs)); ws->slabs = nullptr; ws->slab_bytes = 0; }
+    size_t n = (size_t)32 << 20;   // 32 MiB covers every reference shape on 256 CUs
+    while (n < slab_bytes) n *= 2;
+    WINO_HIP(hipMalloc((void**)&ws->slabs, n));
+    ws->slab_bytes = n;
+  }
+  if (ws->n_tickets < n_tickets) {
+    if (ws->tickets) { WINO_HIP(hipDeviceSynchronize()); WINO_HIP(hipFree(ws->tickets)); ws->tickets = nullptr; ws->n_tickets = 0; }
+    size_t n = 4096;
+    while (n < n_tickets) n *= 2;
+    WINO_HIP(hipMalloc((void**)&ws->tickets, n * sizeof(unsigned)));
+    WINO_HIP(hipMemset(ws->tickets, 0, n * sizeof(unsigned)));
+    ws->n_tickets = n;
+  }
+  *slabs = ws->slabs;
+  *tickets = ws->tickets;
+  return WINO_OK;
+}
+
+int device_cus(int dev, int* cus) {
+  static std::atomic<int> cache[64];
+  int c = dev >= 0 && dev < 64 ? cache[dev].load() : 0;
+  if (!c) {
+    WINO_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cache[dev].store(c);
+  }
+  *cus = c;
+  return WINO_OK;
 }
 
 }  // namespace wino

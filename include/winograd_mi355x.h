@@ -176,6 +176,13 @@ int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const f
 int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, const float* bnScale,
                        const float* residual, float* C, long M, int Cin, int Kout, int flags,
                        wino_stream_t s);
+/* Shapes whose tile count leaves the last round of workgroups mostly empty (the reference's
+ * 512->128 and 1024->256 layers at N = 128: 448 tiles on 256 CUs) are launched in stream-K form
+ * and use library-owned scratch of stream `s`, allocated on the first such launch.  Call this
+ * once per (shape, stream) before capturing the layer into a HIP graph; it launches nothing.
+ * Results do not depend on the launch form chosen beyond fp32 summation order, and are bitwise
+ * reproducible from launch to launch.  WINO_1X1_SK=0 in the environment disables the form. */
+int wino_conv1x1_prepare(long M, int Cin, int Kout, wino_stream_t s);
 
 /* ---- ResNet bottleneck block of the 14x14 stage (BASELINE.json configs[4]) ---------
  * out = relu( bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x, w1))), U2))), w3)) + x )

@@ -391,6 +391,86 @@ def test_one_by_one_full_size(name, pkg, O, torch_dev):
     assert O.rel_error(got, pkg.conv1x1_direct(At, Bt, bt, st, relu).cpu().numpy()) < TIGHT
 
 
+@pytest.mark.parametrize("M,Cin,Kout", [(196, 1024, 256), (1000, 512, 128), (3 * 196, 256, 1024), (2500, 128, 512), (113, 64, 64)])
+def test_one_by_one_streamk_decompositions_agree(M, Cin, Kout, pkg, O, torch_dev, monkeypatch):
+    """The 1x1 kernel's stream-K form cuts tiles x k-steps into G equal ranges; a tile cut by a range
+    boundary is finished by whichever workgroup draws its last ticket, which adds the segments'
+    slabs in k order.  Every G must agree with the fp64 oracle and with the plain launch (to
+    rounding: the cuts move the order of the channel sum), every G must be bitwise reproducible,
+    and the tile counters must be back at zero (the second launch of a pair relies on it).  Small
+    G gives long ranges (whole tiles in the middle), large G tiles cut into many segments."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(M + Cin)
+    A = ((rng.rand(M, Cin) - 0.5) * 4).astype(np.float32)
+    B = ((rng.rand(Cin, Kout) - 0.5) * 4).astype(np.float32)
+    s = (rng.rand(Kout) - 0.5).astype(np.float32)
+    b = ((rng.rand(Kout) - 0.5) * 4).astype(np.float32)
+    At, Bt, bt, st = (_t(torch_dev, a) for a in (A, B, b, s))
+    want = O.conv1x1_bn(A, B, b, s, True)
+    monkeypatch.setenv("WINO_1X1_SK", "0")
+    monkeypatch.delenv("WINO_1X1_SK_GRID", raising=False)
+    plain = pkg.conv1x1_bn(At, Bt, bt, st, True).clone()
+    assert O.rel_error(plain.cpu().numpy(), want) < TIGHT
+    scale = float(plain.abs().max())
+    monkeypatch.setenv("WINO_1X1_SK", "1")
+    for grid in (None, 8, 16, 40, 104, 256, 512, 1000, 4096):
+        if grid is None:
+            monkeypatch.delenv("WINO_1X1_SK_GRID", raising=False)
+        else:
+            monkeypatch.setenv("WINO_1X1_SK_GRID", str(grid))
+        a = pkg.conv1x1_bn(At, Bt, bt, st, True).clone()
+        c = pkg.conv1x1_bn(At, Bt, bt, st, True)
+        assert torch.equal(a, c), f"grid {grid}: not reproducible"
+        assert O.rel_error(a.cpu().numpy(), want) < TIGHT, f"grid {grid}"
+        assert float((a - plain).abs().max()) < 4e-6 * scale, f"grid {grid}"
+
+
+def test_one_by_one_streamk_flags_and_graph(pkg, O, torch_dev, monkeypatch):
+    """Stream-K form under the chaining flags (padded A, padded C with its zero ring, residual before
+    the ReLU), then captured into a HIP graph after wino_conv1x1_prepare (no allocation inside the
+    capture) and replayed."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(77)
+    N, Cin, Kout = 6, 512, 128
+    A = (rng.rand(N, 14, 14, Cin) - 0.5).astype(np.float32)
+    B = (rng.rand(Cin, Kout) - 0.5).astype(np.float32)
+    s = (rng.rand(Kout) - 0.5).astype(np.float32)
+    b = (rng.rand(Kout) - 0.5).astype(np.float32)
+    R = (rng.rand(N * 196, Kout) - 0.5).astype(np.float32)
+    Ap = rng.rand(N, 16, 16, Cin).astype(np.float32) * 100
+    Ap[:, 1:15, 1:15, :] = A
+    want = O.conv1x1_bn(A.reshape(-1, Cin), B, b, s, True)
+    want_res = np.maximum(O.conv1x1_bn(A.reshape(-1, Cin), B, b, s, False) + R, 0)
+    monkeypatch.setenv("WINO_1X1_SK", "1")
+    for grid in ("24", "200"):
+        monkeypatch.setenv("WINO_1X1_SK_GRID", grid)
+        out = torch.full((N, 16, 16, Kout), float("nan"), device=dev)
+        pkg.conv1x1_bn_ex(_t(torch_dev, Ap), _t(torch_dev, B), _t(torch_dev, b), _t(torch_dev, s),
+                          pkg.RELU | pkg.A_PADDED | pkg.C_PADDED, out=out)
+        got = out.cpu().numpy()
+        assert O.rel_error(got[:, 1:15, 1:15, :].reshape(-1, Kout), want) < TIGHT
+        assert (got[:, _ring(), :] == 0).all()
+        got3 = pkg.conv1x1_bn_ex(_t(torch_dev, A), _t(torch_dev, B), _t(torch_dev, b), _t(torch_dev, s),
+                                 pkg.RELU | pkg.ADD_RESIDUAL, residual=_t(torch_dev, R)).cpu().numpy()
+        assert O.rel_error(got3, want_res) < TIGHT
+    # graph capture on a side stream: scratch allocated by prepare, outside the capture
+    monkeypatch.setenv("WINO_1X1_SK_GRID", "200")
+    At, Bt, bt, st = (_t(torch_dev, a) for a in (A.reshape(-1, Cin), B, b, s))
+    outg = torch.zeros(N * 196, Kout, device=dev)
+    sg = torch.cuda.Stream()
+    with torch.cuda.stream(sg):
+        pkg.conv1x1_prepare(N * 196, Cin, Kout)
+    sg.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=sg):
+        pkg.conv1x1_bn(At, Bt, bt, st, True, out=outg)
+    for _ in range(3):
+        outg.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert O.rel_error(outg.cpu().numpy(), want) < TIGHT
+
+
 # ------------------------------------------------------------------ chaining (SURVEY 8f)
 def test_conv1x1_padded_in_out_and_residual(pkg, O, torch_dev):
     torch, dev = torch_dev
