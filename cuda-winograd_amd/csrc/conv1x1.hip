@@ -63,24 +63,28 @@ using namespace wino;
 // forces the plain / stream-K form (1: whenever a legal grid exists), WINO_1X1_SK_GRID=G sets the
 // number of ranges (rounded down to a multiple of 8, at most one range per k-step).
 constexpr int SK1_MIN_STEPS = 8, SK1_AUTO_STEPS = 24;
-static int sk1_grid(long long tiles, int nk, int cus) {
+static int sk1_grid(long long tiles, int nk, int cus, int nblk) {
   const char* f_env = getenv("WINO_1X1_SK");
   const char* g_env = getenv("WINO_1X1_SK_GRID");
   const int force = f_env && *f_env ? atoi(f_env) : -1;
   if (force == 0 || cus < 8 || tiles < 1) return 0;
   const long long U = tiles * nk;
+  // G is a multiple of 8 (whole XCD groups) and of the column blocks per row tile (a range is
+  // run by one workgroup per column block)
+  long long step = 8;
+  while (step % nblk) step += 8;
   if (g_env && *g_env) {
     long long G = atoll(g_env);
     if (G > U) G = U;
     if (G > (1 << 20)) G = 1 << 20;
-    G &= ~7ll;
-    return G >= 8 ? (int)G : 0;
+    G -= G % step;
+    return G >= step ? (int)G : 0;
   }
   const long long rounds = (tiles + cus - 1) / cus;
   long long G = rounds * cus;
   if (G > U / SK1_MIN_STEPS) G = U / SK1_MIN_STEPS;
-  G &= ~7ll;                                   // whole XCD groups
-  if (G < 8 || G <= tiles) return 0;           // nothing to split
+  G -= G % step;
+  if (G < step || G <= tiles) return 0;        // nothing to split
   if (G > (1 << 20)) return 0;
   if (force == 1) return (int)G;
   const double waste = (double)(rounds * cus) / (double)tiles - 1.0;
@@ -106,7 +110,7 @@ static int launch_1x1(const float* A, const float* B, const float* bnBias, const
   int cus = 0;
   if (int rc = device_cus(dev, &cus)) return rc;
   const long long tiles = (long long)nMB * (Kout / G::BN);
-  const int Gsk = batch == 1 ? sk1_grid(tiles, Cin / BK, cus) : 0;
+  const int Gsk = batch == 1 ? sk1_grid(tiles, Cin / BK, cus, Kout / G::BN) : 0;
   if (Gsk) {
     SkArgs sk{nullptr, nullptr};
     if (int rc = sk_scratch(dev, s, (size_t)2 * Gsk * NW * RB * 1024, (size_t)tiles, &sk.slabs, &sk.tickets)) return rc;
