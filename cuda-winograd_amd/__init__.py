@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "wino_event_record", "wino_event_elapsed_ms", "wino_filter_f2_elems", "wino_filter_f2_index",
     "wino_filter_transform_f2", "wino_filter_import_f4", "wino_conv3x3_bn_relu", "wino_conv3x3_prepare",
     "wino_conv3x3_bn_relu_hw", "wino_conv3x3_prepare_hw", "wino_conv3x3_direct_hw", "wino_conv3x3_plan",
-    "wino_conv1x1_prepare",
+    "wino_conv1x1_prepare", "wino_conv1x1_plan",
     "wino_conv3x3_f4_bn_relu", "wino_conv3x3_f4_workspace_bytes",
     "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_bn_ex", "wino_conv1x1_direct",
     "wino_residual_block", "wino_residual_block_workspace_bytes", "wino_driver_set_batch",
@@ -78,6 +78,7 @@ def lib() -> ctypes.CDLL:
     L.wino_conv3x3_bn_relu.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_prepare.argtypes = [c_int, c_int, c_int, c_void_p]
     L.wino_conv1x1_prepare.argtypes = [c_long, c_int, c_int, c_void_p]
+    L.wino_conv1x1_plan.argtypes = [c_long, c_int, c_int, c_int] + [POINTER(c_int)] * 5
     L.wino_conv3x3_bn_relu_hw.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_prepare_hw.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p]
     L.wino_conv3x3_f4_workspace_bytes.restype = c_size_t

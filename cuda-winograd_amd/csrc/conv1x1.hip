@@ -52,6 +52,13 @@ __global__ void conv1x1_direct_kernel(const float* __restrict__ A, const float* 
 
 using namespace wino;
 
+// 4-wave workgroups (64 columns) or 8-wave (128 columns).  Four when Kout is small: twice the
+// workgroups, so that at the reference's Kout = 128 every CU holds two of them; when Cin is small
+// (few k-steps per workgroup: 128->512 measured 35.1 vs 37.1 us; otherwise equal to 8 waves within
+// 1 %); and whenever Kout is not a multiple of 128 -- the API takes any multiple of 64, and a
+// 128-column block would leave the last 64 columns uncomputed.
+static inline bool four_waves(int Cin, int Kout) { return Kout <= 128 || Cin <= 128 || (Kout % 128) != 0; }
+
 // Stream-K grid for `tiles` output tiles of nk k-steps on `cus` CUs, or 0 for the plain
 // one-tile-per-workgroup launch.  A launch costs ceil(tiles / cus) workgroup-times whatever the
 // occupancy (see conv1x1_kernel.h), so the plain form wastes rounds * cus / tiles - 1; stream-K
@@ -63,6 +70,7 @@ using namespace wino;
 // forces the plain / stream-K form (1: whenever a legal grid exists), WINO_1X1_SK_GRID=G sets the
 // number of ranges (rounded down to a multiple of 8, at most one range per k-step).
 constexpr int SK1_MIN_STEPS = 8, SK1_AUTO_STEPS = 24;
+constexpr long long SK1_MAX_GRID = 16384;   // 2 * G slabs of <= 56 KB must stay below the 4 GiB a buffer descriptor spans
 static int sk1_grid(long long tiles, int nk, int cus, int nblk) {
   const char* f_env = getenv("WINO_1X1_SK");
   const char* g_env = getenv("WINO_1X1_SK_GRID");
@@ -76,7 +84,7 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk) {
   if (g_env && *g_env) {
     long long G = atoll(g_env);
     if (G > U) G = U;
-    if (G > (1 << 20)) G = 1 << 20;
+    if (G > SK1_MAX_GRID) G = SK1_MAX_GRID;
     G -= G % step;
     return G >= step ? (int)G : 0;
   }
@@ -85,7 +93,7 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk) {
   if (G > U / SK1_MIN_STEPS) G = U / SK1_MIN_STEPS;
   G -= G % step;
   if (G < step || G <= tiles) return 0;        // nothing to split
-  if (G > (1 << 20)) return 0;
+  if (G > SK1_MAX_GRID) return 0;
   if (force == 1) return (int)G;
   const double waste = (double)(rounds * cus) / (double)tiles - 1.0;
   return waste > 0.06 && tiles >= cus && U / G >= SK1_AUTO_STEPS ? (int)G : 0;
@@ -135,7 +143,7 @@ int gemm_batched(const float* A, const float* B, float* C, long M, int Cin, int 
     return WINO_E_SHAPE;
   }
   const int nMB = (int)((M + BM - 1) / BM);
-  if (Kout <= 128 || Cin <= 128)
+  if (four_waves(Cin, Kout))
     return launch_1x1<32, 4>(A, B, nullptr, nullptr, nullptr, C, M, Cin, Kout, gemm1x1::WINO_INTERNAL_NO_BN, nMB, s,
                              batch, batchA, batchB, batchC);
   return launch_1x1<32, 8>(A, B, nullptr, nullptr, nullptr, C, M, Cin, Kout, gemm1x1::WINO_INTERNAL_NO_BN, nMB, s,
@@ -166,12 +174,31 @@ int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, cons
   // BK = 32 keeps a workgroup at 60 KB of LDS, so two workgroups share a CU (4 waves per SIMD)
   // and one's prologue / barrier bubbles / store tail hide under the other's MFMAs; measured
   // 3-14 % faster than BK = 64 (120 KB, one workgroup per CU) on the four reference shapes.
-  // 4-wave workgroups (64 columns) when Kout is small: twice the workgroups, so that at the
-  // reference's Kout = 128 every CU holds two of them; also when Cin is small (few k-steps per
-  // workgroup: 128->512 measured 35.1 vs 37.1 us), otherwise equal to 8 waves within 1 %
-  if (Kout <= 128 || Cin <= 128)
+  if (four_waves(Cin, Kout))
     return launch_1x1<32, 4>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s);
   return launch_1x1<32, 8>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s);
+}
+
+// Host-side only: the launch form this shape takes on a device with `cus` compute units.
+int wino_conv1x1_plan(long M, int Cin, int Kout, int cus, int* grid, int* row_tiles, int* col_blocks,
+                      int* k_steps, int* stream_k) {
+  if (!grid || !row_tiles || !col_blocks || !k_steps || !stream_k || cus < 1) { set_error("bad argument"); return WINO_E_ARG; }
+  if (M < 1 || Cin <= 0 || Kout <= 0 || (Cin % 32) != 0 || (Kout % 64) != 0) {
+    set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% 64 == 0)",
+              M, Cin, Kout);
+    return WINO_E_SHAPE;
+  }
+  const long nMBl = (M + BM - 1) / BM;
+  if (nMBl > (1L << 24)) { set_error("M too large"); return WINO_E_SHAPE; }
+  const int bn = four_waves(Cin, Kout) ? 64 : 128;   // as wino_conv1x1_bn_ex
+  const int nblk = Kout / bn;
+  const int G = sk1_grid((long long)nMBl * nblk, Cin / 32, cus, nblk);
+  *row_tiles = (int)nMBl;
+  *col_blocks = nblk;
+  *k_steps = Cin / 32;
+  *stream_k = G != 0;
+  *grid = G ? G : 8 * nblk * (int)((nMBl + 7) / 8);
+  return WINO_OK;
 }
 
 // Allocates the stream-K scratch this shape's launches on stream `s` will use (nothing for shapes
@@ -185,7 +212,7 @@ int wino_conv1x1_prepare(long M, int Cin, int Kout, wino_stream_t s) {
   const long nMBl = (M + BM - 1) / BM;
   if (nMBl > (1L << 24)) { set_error("M too large"); return WINO_E_SHAPE; }
   const int nMB = (int)nMBl;
-  if (Kout <= 128 || Cin <= 128)
+  if (four_waves(Cin, Kout))
     return launch_1x1<32, 4>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, Cin, Kout, 0, nMB, (hipStream_t)s, 1, 0, 0, 0, true);
   return launch_1x1<32, 8>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, Cin, Kout, 0, nMB, (hipStream_t)s, 1, 0, 0, 0, true);
 }

@@ -157,7 +157,8 @@ int wino_conv3x3_direct_hw(const float* in, const float* w_kcrs, const float* bn
  * A [M][Cin] (M = N*196 pixels, HWC flat), B [Cin][Kout] row-major, C [M][Kout].
  * C = bnScale[k]*(A.B) + bnBias[k], ReLU if `relu`.  Argument order as the reference
  * kernels (A, B, bnBias, bnScale, C), Kernel128_one.cu:24.
- * Constraints: Cin % 32 == 0, Kout % 64 == 0, M >= 1 (any M: the last row tile is ragged). */
+ * Constraints: Cin % 32 == 0, Kout % 64 == 0 (workgroups are 128 columns wide when Kout % 128 == 0
+ * and both dimensions exceed 128, 64 columns otherwise), M >= 1 (any M: the last row tile is ragged). */
 int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const float* bnScale,
                     float* C, long M, int Cin, int Kout, int relu, wino_stream_t s);
 /* Extended form used when layers are chained (the residual block):
@@ -183,6 +184,14 @@ int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, cons
  * Results do not depend on the launch form chosen beyond fp32 summation order, and are bitwise
  * reproducible from launch to launch.  WINO_1X1_SK=0 in the environment disables the form. */
 int wino_conv1x1_prepare(long M, int Cin, int Kout, wino_stream_t s);
+/* Host-side only (no GPU needed): the launch form of this shape on a device with `cus` compute
+ * units.  The output is `row_tiles` x `col_blocks` tiles (112 rows x 64 or 128 columns) of
+ * `k_steps` = Cin/32 pipeline steps.  stream_k = 0: `grid` workgroups, one whole tile each (some of
+ * the grid may be padding).  stream_k = 1: the (row tile, k-step) space is cut into grid/col_blocks
+ * equal ranges -- range r covers [r*T/R, (r+1)*T/R) of T = row_tiles*k_steps, R = grid/col_blocks --
+ * and logical workgroup r*col_blocks + nb runs range r for column block nb. */
+int wino_conv1x1_plan(long M, int Cin, int Kout, int cus, int* grid, int* row_tiles, int* col_blocks,
+                      int* k_steps, int* stream_k);
 
 /* ---- ResNet bottleneck block of the 14x14 stage (BASELINE.json configs[4]) ---------
  * out = relu( bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x, w1))), U2))), w3)) + x )

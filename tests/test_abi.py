@@ -201,6 +201,80 @@ def test_launch_plan_covers_every_iteration_once(N, H, W, C, K, cus, pkg, monkey
         assert (G, rounds, tail_iters) == (196, 1, 0)
 
 
+def _plan1x1(pkg, M, Cin, Kout, cus):
+    v = [ctypes.c_int() for _ in range(5)]
+    rc = pkg.lib().wino_conv1x1_plan(M, Cin, Kout, cus, *[ctypes.byref(x) for x in v])
+    assert rc == 0, pkg.lib().wino_last_error_string()
+    return [x.value for x in v]
+
+
+@pytest.mark.parametrize("M,Cin,Kout,cus,grid_env", [
+    (25088, 1024, 256, 256, None), (25088, 512, 128, 256, None), (25088, 256, 1024, 256, None),
+    (25088, 128, 512, 256, None), (196, 1024, 256, 256, "16"), (1000, 512, 128, 256, "104"),
+    (588, 256, 1024, 256, "4096"), (2500, 128, 512, 304, "1000"), (113, 64, 64, 8, "8"),
+    (40000, 2048, 192, 256, None), (5000, 96, 192, 64, "48"),
+])
+def test_one_by_one_plan_covers_every_step_once(M, Cin, Kout, cus, grid_env, pkg, monkeypatch):
+    """The 1x1 kernel's stream-K decomposition, replayed on the host the way the kernel walks it:
+    every (tile, k-step) is computed exactly once, a range is cut into whole tiles plus at most one
+    head and one tail segment, no two partial segments share a slab slot, every cut tile's
+    segments come from consecutive ranges (what the finisher's gather assumes), and the ranges are
+    balanced to one step.  The two facts DESIGN.md section 3.2 states for the reference layers."""
+    monkeypatch.delenv("WINO_1X1_SK", raising=False)
+    if grid_env is None:
+        monkeypatch.delenv("WINO_1X1_SK_GRID", raising=False)
+    else:
+        monkeypatch.setenv("WINO_1X1_SK", "1")
+        monkeypatch.setenv("WINO_1X1_SK_GRID", grid_env)
+    G, nMB, nblk, nk, sk = _plan1x1(pkg, M, Cin, Kout, cus)
+    assert nMB == -(-M // 112) and nk == Cin // 32 and Kout % nblk == 0 and Kout // nblk in (64, 128)
+    tiles = nMB * nblk
+    if (M, Cin, Kout, cus, grid_env) == (25088, 1024, 256, 256, None):
+        assert (sk, G) == (1, 512)            # 448 tiles on 256 CUs: 28 of 32 k-steps per range
+    if (M, Cin, Kout, cus, grid_env) in ((25088, 512, 128, 256, None), (25088, 256, 1024, 256, None), (25088, 128, 512, 256, None)):
+        assert sk == 0                        # 14 steps per range: not worth the hand-over; exact rounds
+    if not sk:
+        assert G >= tiles and G % (8 * nblk) == 0
+        return
+    assert G % 8 == 0 and G % nblk == 0 and 0 < G <= 16384 and G <= tiles * nk
+    R, T = G // nblk, nMB * nk
+    seen = np.zeros((nMB, nk), np.int32)
+    slots, loads, owners = set(), [], {}
+    for r in range(R):
+        u, uend = T * r // R, T * (r + 1) // R
+        assert uend > u                       # no empty range: the finisher counts ranges, not segments
+        loads.append(uend - u)
+        partial = 0
+        while u < uend:
+            mb, k0 = divmod(u, nk)
+            ln = min(uend - u, nk - k0)
+            seen[mb, k0:k0 + ln] += 1
+            if not (k0 == 0 and ln == nk):
+                partial += 1
+                slot = 2 * r + (1 if k0 == 0 else 0)
+                assert slot not in slots
+                slots.add(slot)
+                owners.setdefault(mb, []).append((k0, r))
+            u += ln
+        assert partial <= 2
+    assert (seen == 1).all()
+    assert max(loads) - min(loads) <= 1
+    for mb, segs in owners.items():
+        segs.sort()
+        rs = [r for _, r in segs]
+        assert rs == list(range(rs[0], rs[0] + len(rs))) and len(rs) >= 2 and segs[0][0] == 0
+
+
+def test_one_by_one_plan_rejects_bad_shapes(pkg):
+    v = [ctypes.c_int() for _ in range(5)]
+    a = [ctypes.byref(x) for x in v]
+    L = pkg.lib()
+    assert L.wino_conv1x1_plan(100, 48, 128, 256, *a) != 0       # Cin % 32
+    assert L.wino_conv1x1_plan(100, 64, 96, 256, *a) != 0        # Kout % 64
+    assert L.wino_conv1x1_plan(0, 64, 128, 256, *a) != 0         # no rows
+    assert L.wino_conv1x1_plan(100, 64, 128, 0, *a) != 0         # no compute units
+
+
 def test_launch_plan_rejects_bad_shapes(pkg):
     L = pkg.lib()
     g, r, it = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -95,12 +95,13 @@ def test_f4_compat_path_on_reference_files(C, data_dir, pkg, O, golden_outputs, 
     assert O.rel_error(got, f2) < 1e-4
 
 
-def test_f4_compat_path_batched(pkg, O, torch_dev):
+@pytest.mark.parametrize("N,C,K", [(13, 64, 128), (3, 160, 192)])
+def test_f4_compat_path_batched(N, C, K, pkg, O, torch_dev):
     """Batch, several images per row tile of the batched GEMM (M = 16 N not a multiple of 112),
     C != K, no ReLU: against the fp64 direct convolution with filters transformed the reference's
-    way (G g G^T in fp64, stored fp32)."""
+    way (G g G^T in fp64, stored fp32).  K = 192 with C > 128: a column count that is a multiple of
+    64 but not of 128 (the batched GEMM must take its 64-column form)."""
     rng = np.random.RandomState(91)
-    N, C, K = 13, 64, 128
     x, w, s, b = _rand_layer(rng, N, C, K)
     G = O.G_F4
     u36 = np.einsum('xr,kcrs,ys->xyck', G, w.astype(np.float64), G).reshape(36, C, K).astype(np.float32)
@@ -375,6 +376,24 @@ def test_one_by_one_ragged_rows(M, pkg, O, torch_dev):
         assert O.rel_error(got.cpu().numpy(), O.conv1x1_bn(A, B, b, s, relu)) < TIGHT
 
 
+@pytest.mark.parametrize("M,Cin,Kout", [(700, 256, 192), (333, 512, 320), (1500, 160, 448), (112, 1024, 64)])
+def test_one_by_one_column_counts(M, Cin, Kout, pkg, O, torch_dev):
+    """Kout is any multiple of 64: with a large Cin the 128-column workgroup form would leave the last
+    64 columns of Kout = 192, 320, 448 uncomputed.  Every column against the fp64 oracle, on an
+    output buffer pre-filled with NaN."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(Kout)
+    A = ((rng.rand(M, Cin) - 0.5) * 4).astype(np.float32)
+    B = ((rng.rand(Cin, Kout) - 0.5) * 4).astype(np.float32)
+    s = (rng.rand(Kout) - 0.5).astype(np.float32)
+    b = ((rng.rand(Kout) - 0.5) * 4).astype(np.float32)
+    out = torch.full((M, Kout), float("nan"), device=dev)
+    pkg.conv1x1_bn(_t(torch_dev, A), _t(torch_dev, B), _t(torch_dev, b), _t(torch_dev, s), False, out=out)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert O.rel_error(got, O.conv1x1_bn(A, B, b, s, False)) < TIGHT
+
+
 @pytest.mark.parametrize("name", ["kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in", "kernel_256_1_out"])
 def test_one_by_one_full_size(name, pkg, O, torch_dev):
     """BASELINE configs[3]: N = 128 -> M = 25088 rows, against the fp64 GEMM oracle."""
@@ -391,7 +410,7 @@ def test_one_by_one_full_size(name, pkg, O, torch_dev):
     assert O.rel_error(got, pkg.conv1x1_direct(At, Bt, bt, st, relu).cpu().numpy()) < TIGHT
 
 
-@pytest.mark.parametrize("M,Cin,Kout", [(196, 1024, 256), (1000, 512, 128), (3 * 196, 256, 1024), (2500, 128, 512), (113, 64, 64)])
+@pytest.mark.parametrize("M,Cin,Kout", [(196, 1024, 256), (1000, 512, 128), (3 * 196, 256, 1024), (2500, 128, 512), (113, 64, 64), (700, 256, 192)])
 def test_one_by_one_streamk_decompositions_agree(M, Cin, Kout, pkg, O, torch_dev, monkeypatch):
     """The 1x1 kernel's stream-K form cuts tiles x k-steps into G equal ranges; a tile cut by a range
     boundary is finished by whichever workgroup draws its last ticket, which adds the segments'
