@@ -521,7 +521,7 @@ def test_conv1x1_padded_in_out_and_residual(pkg, O, torch_dev):
     assert O.rel_error(got3, want3) < TIGHT
 
 
-@pytest.mark.parametrize("N,C4,Cm", [(2, 256, 128), (5, 1024, 256)])
+@pytest.mark.parametrize("N,C4,Cm", [(2, 256, 128), (5, 1024, 256), (3, 384, 192)])
 def test_residual_block(N, C4, Cm, pkg, O, torch_dev):
     """BASELINE configs[4]: 1x1 -> 3x3 -> 1x1 + skip, against the fp64 composition of the layer
     oracles.  Weights are scaled so that activations stay O(1) through the block."""
@@ -539,6 +539,54 @@ def test_residual_block(N, C4, Cm, pkg, O, torch_dev):
     assert got.shape == want.shape
     assert O.rel_error(got, want) < TIGHT
     assert (want > 0).mean() > 0.2  # the test exercises both sides of the final ReLU
+
+
+# ------------------------------------------------------------------ random legal shapes
+def test_random_legal_shapes(pkg, O, torch_dev):
+    """Seeded sweep over shapes the C-ABI declares legal (1x1: any M, Cin % 32, Kout % 64; 3x3: any
+    N, H, W, C % 8, K % 64), each against the fp64 oracle on an output pre-filled with NaN: the
+    corners between the hand-picked cases (a column count that is a multiple of 64 but not of
+    128 went uncomputed until a sweep like this one).  Stream-K forms are forced on every other
+    1x1 case so that both launch forms see odd shapes."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(2024)
+    t = lambda a: _t(torch_dev, a)
+    for i in range(24):
+        M = int(rng.randint(1, 2600)); Cin = 32 * int(rng.randint(1, 20)); Kout = 64 * int(rng.randint(1, 11))
+        A = ((rng.rand(M, Cin) - 0.5) * 4).astype(np.float32)
+        B = ((rng.rand(Cin, Kout) - 0.5) * 4).astype(np.float32)
+        s = (rng.rand(Kout) - 0.5).astype(np.float32)
+        b = ((rng.rand(Kout) - 0.5) * 4).astype(np.float32)
+        relu = bool(i & 1)
+        if i % 2:
+            os.environ["WINO_1X1_SK"] = "1"
+            os.environ["WINO_1X1_SK_GRID"] = str(8 * int(rng.randint(1, 64)))
+        try:
+            out = torch.full((M, Kout), float("nan"), device=dev)
+            pkg.conv1x1_bn(t(A), t(B), t(b), t(s), relu, out=out)
+            got = out.cpu().numpy()
+        finally:
+            os.environ.pop("WINO_1X1_SK", None)
+            os.environ.pop("WINO_1X1_SK_GRID", None)
+        assert np.isfinite(got).all(), (M, Cin, Kout)
+        assert O.rel_error(got, O.conv1x1_bn(A, B, b, s, relu)) < TIGHT, (M, Cin, Kout)
+    for i in range(16):
+        N = int(rng.randint(1, 6)); H = int(rng.randint(1, 21)); W = int(rng.randint(1, 21))
+        C = 8 * int(rng.randint(1, 20)); K = 64 * int(rng.randint(1, 4))
+        x = (rng.rand(N, H + 2, W + 2, C) - 0.5).astype(np.float32)
+        w = (rng.rand(K, C, 3, 3) - 0.5).astype(np.float32)
+        s = (rng.rand(K) - 0.5).astype(np.float32)
+        b = (rng.rand(K) - 0.5).astype(np.float32)
+        relu = bool(i & 1)
+        U = pkg.filter_transform_f2(t(w))
+        out = torch.full((N, H + 2, W + 2, K), float("nan"), device=dev)
+        pkg.conv3x3_bn_relu(t(x), U, t(b), t(s), relu=relu, out=out)
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all(), (N, H, W, C, K)
+        want = O.conv3x3_bn_relu_direct(x, w, s, b, relu=relu)
+        assert O.rel_error(got, want) < TIGHT, (N, H, W, C, K)
+        ring = np.ones((H + 2, W + 2), bool); ring[1:-1, 1:-1] = False
+        assert (got[:, ring, :] == 0).all(), (N, H, W, C, K)
 
 
 # ------------------------------------------------------------------ errors
