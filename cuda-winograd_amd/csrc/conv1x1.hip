@@ -60,18 +60,37 @@ using namespace wino;
 static inline bool four_waves(int Cin, int Kout) { return Kout <= 128 || Cin <= 128 || (Kout % 128) != 0; }
 
 // Stream-K grid for `tiles` output tiles of nk k-steps on `cus` CUs, or 0 for the plain
-// one-tile-per-workgroup launch.  A launch costs ceil(tiles / cus) workgroup-times whatever the
-// occupancy (see conv1x1_kernel.h), so the plain form wastes rounds * cus / tiles - 1; stream-K
-// runs G = rounds * cus equal ranges instead and pays one slab round trip per range.  Taken when
-// the waste is above 6 % and a range keeps at least SK1_AUTO_STEPS k-steps (the hand-over sits at
-// the end of every range, on the launch's critical path: measured at N = 128, 1024->256 with 28
-// steps per range 118 -> 111 us, 512->128 with 14 steps per range 33 -> 35 us).
+// one-tile-per-workgroup launch.  A launch lasts as long as its busiest CU (conv1x1_kernel.h): the
+// plain form puts r = ceil(tiles / cus) whole tiles on it, stream-K x = tiles * nk / cus k-steps
+// plus a hand-over per range, at the end of the range, on the critical path.  Launch times in us
+// fitted to ~60 measurements on MI355X (the four reference layers, N = 1..192, G = cus and 2 cus;
+// reproduced to 1-3 %):
+//                        8 waves (128 columns)              4 waves (64 columns)
+//   plain                3 + r (1.80 nk + 0.9)              5.3 + r (0.82 nk + 0.7)
+//   stream-K, G = cus    11 + x (1.79 + 0.9 / nk)           9 + x (0.96 + 0.7 / nk)
+//   stream-K, G = 2 cus  15 + x (1.67 + 0.9 / nk)           12 + x (0.80 + 0.7 / nk)
+// (the 0.9 / 0.7 is a whole tile's epilogue; two ranges per CU run the steps a little faster and pay
+// a second hand-over).  The cheapest predicted form wins; stream-K must come in under 0.96 of plain.
+// What that buys at the reference shapes: 1024->256 N = 128 118 -> 109 us, N = 80..112 116 -> 73..98,
+// N = 160 171 -> 133; 512->128 N = 80 32 -> 27, N = 160 47 -> 42, N = 128 stays plain (32 vs 35).
+//
+// Tiny problems -- fewer k-steps than 4 per CU, the reference's own N = 1 protocol -- leave CUs idle
+// in any form; split-K over G = steps / 4 ranges (a tile's 4-16 segments gathered in k order by
+// whoever arrives last): 1024->256 59 -> 19-25 us for N <= 16, 512->128 18 -> 11-13 us.  Taken when
+// the K loop has at least 16 steps and a range plus its hand-over (about 5 steps) stays below 0.8 of
+// a plain workgroup's nk + 1.6 (epilogue) steps: 256->1024 (8 steps) would gain < 25 % at N <= 2 and
+// lose from N = 16, 128->512 (4 steps) always loses.
+//
 // Developer overrides, read per call so that tests can sweep the decomposition: WINO_1X1_SK=0 / 1
 // forces the plain / stream-K form (1: whenever a legal grid exists), WINO_1X1_SK_GRID=G sets the
-// number of ranges (rounded down to a multiple of 8, at most one range per k-step).
-constexpr int SK1_MIN_STEPS = 8, SK1_AUTO_STEPS = 24;
+// number of ranges (rounded down to a multiple of 8 and of the column blocks, at most one range
+// per k-step).
+constexpr int SK1_SMALL_STEPS = 4, SK1_SMALL_MIN_NK = 16, SK1_MIN_STEPS = 4;
 constexpr long long SK1_MAX_GRID = 16384;   // 2 * G slabs of <= 56 KB must stay below the 4 GiB a buffer descriptor spans
-static int sk1_grid(long long tiles, int nk, int cus, int nblk) {
+struct Sk1Model { double a_plain, t_plain, e_tile, a_sk1, t_sk1, a_sk2, t_sk2; };
+constexpr Sk1Model SK1_MODEL_8W = {3.0, 1.80, 0.9, 11.0, 1.79, 15.0, 1.67};
+constexpr Sk1Model SK1_MODEL_4W = {5.3, 0.82, 0.7, 9.0, 0.96, 12.0, 0.80};
+static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_form) {
   const char* f_env = getenv("WINO_1X1_SK");
   const char* g_env = getenv("WINO_1X1_SK_GRID");
   const int force = f_env && *f_env ? atoi(f_env) : -1;
@@ -88,15 +107,28 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk) {
     G -= G % step;
     return G >= step ? (int)G : 0;
   }
+  if (U / SK1_SMALL_STEPS < cus) {   // tiny: split-K, fewer ranges than CUs
+    long long G = U / SK1_SMALL_STEPS;
+    G -= G % step;
+    if (G < step || G <= tiles) return 0;
+    if (force == 1) return (int)G;
+    const double sk_steps = (double)U / (double)G + 5.0, plain_steps = nk + 1.6;
+    return nk >= SK1_SMALL_MIN_NK && sk_steps < 0.8 * plain_steps ? (int)G : 0;
+  }
+  const Sk1Model& m = four_wave_form ? SK1_MODEL_4W : SK1_MODEL_8W;
   const long long rounds = (tiles + cus - 1) / cus;
-  long long G = rounds * cus;
-  if (G > U / SK1_MIN_STEPS) G = U / SK1_MIN_STEPS;
-  G -= G % step;
-  if (G < step || G <= tiles) return 0;        // nothing to split
-  if (G > SK1_MAX_GRID) return 0;
+  const double x = (double)U / (double)cus;
+  const double t_plain = m.a_plain + (double)rounds * (m.t_plain * nk + m.e_tile);
+  long long G1 = cus, G2 = 2ll * cus;
+  G1 -= G1 % step;
+  G2 -= G2 % step;
+  if (G2 > SK1_MAX_GRID || U / G2 < SK1_MIN_STEPS) G2 = 0;
+  if (G1 < step) return 0;
+  const double t_sk1 = m.a_sk1 + x * (m.t_sk1 + m.e_tile / nk);
+  const double t_sk2 = G2 ? m.a_sk2 + x * (m.t_sk2 + m.e_tile / nk) : 1e30;
+  const long long G = t_sk2 < t_sk1 ? G2 : G1;
   if (force == 1) return (int)G;
-  const double waste = (double)(rounds * cus) / (double)tiles - 1.0;
-  return waste > 0.06 && tiles >= cus && U / G >= SK1_AUTO_STEPS ? (int)G : 0;
+  return (t_sk2 < t_sk1 ? t_sk2 : t_sk1) < 0.96 * t_plain ? (int)G : 0;
 }
 
 template <int BK, int NW>
@@ -118,7 +150,7 @@ static int launch_1x1(const float* A, const float* B, const float* bnBias, const
   int cus = 0;
   if (int rc = device_cus(dev, &cus)) return rc;
   const long long tiles = (long long)nMB * (Kout / G::BN);
-  const int Gsk = batch == 1 ? sk1_grid(tiles, Cin / BK, cus, Kout / G::BN) : 0;
+  const int Gsk = batch == 1 ? sk1_grid(tiles, Cin / BK, cus, Kout / G::BN, NW == 4) : 0;
   if (Gsk) {
     SkArgs sk{nullptr, nullptr};
     if (int rc = sk_scratch(dev, s, (size_t)2 * Gsk * NW * RB * 1024, (size_t)tiles, &sk.slabs, &sk.tickets)) return rc;
@@ -192,7 +224,7 @@ int wino_conv1x1_plan(long M, int Cin, int Kout, int cus, int* grid, int* row_ti
   if (nMBl > (1L << 24)) { set_error("M too large"); return WINO_E_SHAPE; }
   const int bn = four_waves(Cin, Kout) ? 64 : 128;   // as wino_conv1x1_bn_ex
   const int nblk = Kout / bn;
-  const int G = sk1_grid((long long)nMBl * nblk, Cin / 32, cus, nblk);
+  const int G = sk1_grid((long long)nMBl * nblk, Cin / 32, cus, nblk, four_waves(Cin, Kout));
   *row_tiles = (int)nMBl;
   *col_blocks = nblk;
   *k_steps = Cin / 32;

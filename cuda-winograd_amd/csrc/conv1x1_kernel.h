@@ -2,14 +2,16 @@
 // (tools/ablate_1x1.hip) compile the same source.  ABLATE (0 = product): 1 skip the A LDS-DMA,
 // 2 skip the B LDS-DMA, 4 skip the MFMAs, 8 skip the per-stage wait+barrier, 512 skip the stores.
 //
-// SK = true is the stream-K launch form.  A workgroup's duration does not depend on whether it
-// shares its CU (measured: 384, 448 and 512 workgroups of the 1024->256 layer all take 116 us, every
-// further 256 add 57 us), so a launch costs ceil(tiles / CUs) workgroup-times and the reference's
-// 448-tile layers pay for 512.  Stream-K cuts the tiles x k-steps space into G = CUs * ceil(tiles /
-// CUs) equal contiguous ranges instead; a range is at most two segments (the tail of one tile, the
-// head of the next).  A segment that is not a whole tile stores its raw accumulators as a
-// write-through slab and the workgroup draws one ticket on the tile; whoever draws the tile's last
-// ticket adds all of its segments' slabs in k order (bitwise reproducible) and runs the epilogue.
+// SK = true is the stream-K launch form.  A launch lasts as long as its busiest CU: a CU gives its
+// workgroups a fixed throughput (one alone walks 32 k-steps of the 1024->256 layer in 57 us, two
+// that share it take 115 us each), so the plain form costs ceil(tiles / CUs) tile-times (measured:
+// 384, 448 and 512 workgroups 116-117 us, every further 256 add 57 us) and the reference's 448-tile
+// layers pay for 512; with fewer tiles than CUs it leaves CUs idle while the busy ones walk whole K
+// loops.  Stream-K cuts the (row tile, k-step) space into equal contiguous ranges instead; a range
+// is a run of whole tiles with at most one cut tile at either end.  A segment that is not a
+// whole tile stores its raw accumulators as a write-through slab and the workgroup draws one
+// ticket on the tile; whoever learns that the tile's other segments are all there adds them in k
+// order (bitwise reproducible) and runs the epilogue.
 // Nobody waits for anybody.  Same slab / ticket rules as the fused 3x3 kernel (wino_f2_fused_kernel.h).
 #pragma once
 #include "wino_common.h"

@@ -213,6 +213,8 @@ def _plan1x1(pkg, M, Cin, Kout, cus):
     (25088, 128, 512, 256, None), (196, 1024, 256, 256, "16"), (1000, 512, 128, 256, "104"),
     (588, 256, 1024, 256, "4096"), (2500, 128, 512, 304, "1000"), (113, 64, 64, 8, "8"),
     (40000, 2048, 192, 256, None), (5000, 96, 192, 64, "48"),
+    (196, 1024, 256, 256, None), (196, 512, 128, 256, None), (196, 256, 1024, 256, None), (196, 128, 512, 256, None),
+    (32 * 196, 1024, 256, 256, None), (64 * 196, 1024, 256, 256, None),
 ])
 def test_one_by_one_plan_covers_every_step_once(M, Cin, Kout, cus, grid_env, pkg, monkeypatch):
     """The 1x1 kernel's stream-K decomposition, replayed on the host the way the kernel walks it:
@@ -233,6 +235,12 @@ def test_one_by_one_plan_covers_every_step_once(M, Cin, Kout, cus, grid_env, pkg
         assert (sk, G) == (1, 512)            # 448 tiles on 256 CUs: 28 of 32 k-steps per range
     if (M, Cin, Kout, cus, grid_env) in ((25088, 512, 128, 256, None), (25088, 256, 1024, 256, None), (25088, 128, 512, 256, None)):
         assert sk == 0                        # 14 steps per range: not worth the hand-over; exact rounds
+    # small batches (fewer tiles than CUs): split-K when the K loop is long enough to pay for the hand-over
+    small = {(196, 1024, 256): (1, 32), (196, 512, 128): (1, 16), (196, 256, 1024): (0, None), (196, 128, 512): (0, None),
+             (32 * 196, 1024, 256): (1, 256), (64 * 196, 1024, 256): (0, None)}
+    if grid_env is None and cus == 256 and (M, Cin, Kout) in small:
+        want_sk, want_G = small[(M, Cin, Kout)]
+        assert sk == want_sk and (want_G is None or G == want_G)
     if not sk:
         assert G >= tiles and G % (8 * nblk) == 0
         return
