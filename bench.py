@@ -39,6 +39,10 @@ LAYERS = {
     "conv1x1_1024_256": ("1x1", 1024, 256, True),
     "conv1x1_256_1024": ("1x1", 256, 1024, False),
     "residual_block": ("block", 1024, 256, True),   # configs[4]: 1x1 1024->256, 3x3 256, 1x1 256->1024 + skip
+    # the bottleneck block of ResNet's other stages (not in the reference), same FLOPs
+    "residual_block_56x56": ("block", 256, 64, True),
+    "residual_block_28x28": ("block", 512, 128, True),
+    "residual_block_7x7": ("block", 2048, 512, True),
     # SURVEY section 8f rank 4 (not in the reference): the 3x3 layers of ResNet's other stages
     "conv3x3_64_56x56": ("3x3", 64, 64, True),
     "conv3x3_128_28x28": ("3x3", 128, 128, True),
@@ -46,20 +50,21 @@ LAYERS = {
     # the reference's own unfused F(4x4,3x3) arithmetic on its weight_winograd file
     "conv3x3_256_f4compat": ("3x3f4", 256, 256, True),
 }
-FEATURE_MAP = {"conv3x3_64_56x56": 56, "conv3x3_128_28x28": 28, "conv3x3_512_7x7": 7}   # default 14
+FEATURE_MAP = {"conv3x3_64_56x56": 56, "conv3x3_128_28x28": 28, "conv3x3_512_7x7": 7,
+               "residual_block_56x56": 56, "residual_block_28x28": 28, "residual_block_7x7": 7}   # default 14
 BATCH = 128
 
 
 def algorithmic_flops(kind: str, N: int, C: int, K: int, H: int = 14) -> float:
     if kind == "block":   # C = outer width (1024), K = bottleneck width (256): 436.7 MFLOP / image
-        return 2.0 * N * 14 * 14 * (C * K + K * K * 9 + K * C)
+        return 2.0 * N * H * H * (C * K + K * K * 9 + K * C)
     return 2.0 * N * H * H * K * C * (9 if kind in ("3x3", "3x3f4") else 1)
 
 
 def executed_mfma_flops(kind: str, N: int, C: int, K: int, H: int = 14) -> float:
     """FLOPs the MFMA pipes execute: F(2x2,3x3) = 16 points x (N*(H/2)^2 tiles) x C x K x 2."""
     if kind == "block":
-        return 2.0 * N * 14 * 14 * 2 * C * K + 2.0 * 16 * N * 49 * K * K
+        return 2.0 * N * H * H * 2 * C * K + 2.0 * 16 * N * ((H + 1) // 2) ** 2 * K * K
     if kind == "3x3f4":   # 36 points x 16 tiles per image
         return 2.0 * 36 * N * 16 * C * K
     return 2.0 * 16 * N * ((H + 1) // 2) ** 2 * C * K if kind == "3x3" else algorithmic_flops(kind, N, C, K)
@@ -223,12 +228,12 @@ def main():
         step = lambda: L.wino_conv3x3_f4_bn_relu(x.data_ptr(), u36.data_ptr(), bias_v.data_ptr(), scale_v.data_ptr(),
                                                  out.data_ptr(), N, C, K, 1, ws.data_ptr(), nbytes, stream)
     elif kind == "block":
-        x = rnd(N, 14, 14, C)
+        x = rnd(N, H, H, C)
         w1, w3 = rnd(C, K, scale=4.0 / C ** 0.5), rnd(K, C, scale=4.0 / K ** 0.5)
         U2 = pkg.filter_transform_f2(rnd(K, K, 3, 3, scale=4.0 / (9 * K) ** 0.5))
         bn1, bn2, bn3 = (rnd(K), rnd(K) + 1.0), (rnd(K), rnd(K) + 1.0), (rnd(C), rnd(C) + 1.0)
         out = torch.empty_like(x)
-        ws = torch.empty(pkg.lib().wino_residual_block_workspace_bytes(N, K) // 4, device=dev)
+        ws = torch.empty(pkg.lib().wino_residual_block_workspace_bytes_hw(N, H, H, K) // 4, device=dev)
         step = lambda: pkg.residual_block(x, w1, bn1, U2, bn2, w3, bn3, out=out, workspace=ws)
     else:
         A = rnd(N * 196, C, scale=40.0)
@@ -293,7 +298,7 @@ def main():
         "config": {"workload": (f"{kind} conv {C}->{K} + folded BN" + (" + ReLU" if relu else "") +
                                 f", {H}x{H} ({H + 2}x{H + 2} padded NHWC), N={N} per GPU, fp32") if kind != "block" else
                                f"ResNet bottleneck 1x1 {C}->{K}, 3x3 {K}->{K}, 1x1 {K}->{C} + skip (BN+ReLU fused), "
-                               f"14x14, N={N} per GPU, fp32",
+                               f"{H}x{H}, N={N} per GPU, fp32",
                    "algorithm": {"3x3": "fused Winograd F(2x2,3x3), one HIP launch",
                                  "3x3f4": "unfused Winograd F(4x4,3x3) compatibility path: transform, batched MFMA GEMM, inverse (4 launches)",
                                  "1x1": "fp32 MFMA GEMM, one HIP launch",

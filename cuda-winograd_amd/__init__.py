@@ -30,7 +30,8 @@ ABI_SYMBOLS = [
     "wino_event_record", "wino_event_elapsed_ms", "wino_filter_f2_elems", "wino_filter_f2_index",
     "wino_filter_transform_f2", "wino_filter_import_f4", "wino_conv3x3_bn_relu", "wino_conv3x3_prepare",
     "wino_conv3x3_bn_relu_hw", "wino_conv3x3_prepare_hw", "wino_conv3x3_direct_hw", "wino_conv3x3_plan",
-    "wino_conv1x1_prepare", "wino_conv1x1_plan",
+    "wino_conv1x1_prepare", "wino_conv1x1_plan", "wino_conv1x1_bn_ex_hw", "wino_residual_block_hw",
+    "wino_residual_block_workspace_bytes_hw",
     "wino_conv3x3_f4_bn_relu", "wino_conv3x3_f4_workspace_bytes",
     "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_bn_ex", "wino_conv1x1_direct",
     "wino_residual_block", "wino_residual_block_workspace_bytes", "wino_driver_set_batch",
@@ -93,6 +94,10 @@ def lib() -> ctypes.CDLL:
     L.wino_residual_block_workspace_bytes.restype = c_size_t
     L.wino_residual_block_workspace_bytes.argtypes = [c_int, c_int]
     L.wino_residual_block.argtypes = [fp] * 11 + [c_int, c_int, c_int, fp, c_size_t, c_void_p]
+    L.wino_conv1x1_bn_ex_hw.argtypes = [fp, fp, fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    L.wino_residual_block_workspace_bytes_hw.restype = c_size_t
+    L.wino_residual_block_workspace_bytes_hw.argtypes = [c_int, c_int, c_int, c_int]
+    L.wino_residual_block_hw.argtypes = [fp] * 11 + [c_int] * 5 + [fp, c_size_t, c_void_p]
     L.wino_device_count.argtypes = [POINTER(c_int)]
     L.wino_driver_last_result.argtypes = [POINTER(DriverResult)]
     L.wino_driver_set_batch.argtypes = [c_int]
@@ -242,50 +247,77 @@ def conv1x1_prepare(M: int, Cin: int, Kout: int) -> None:
     _check(lib().wino_conv1x1_prepare(int(M), int(Cin), int(Kout), _stream()), "wino_conv1x1_prepare")
 
 
-def conv1x1_bn_ex(A, B, bn_bias, bn_scale, flags: int, residual=None, out=None) -> torch.Tensor:
-    """Chaining form of the 1x1 layer: A and/or C may be the padded [N][16][16][.] tensors of the
-    3x3 layer (flags A_PADDED / C_PADDED), a residual [M][Kout] may be added before the ReLU."""
+def conv1x1_bn_ex(A, B, bn_bias, bn_scale, flags: int, residual=None, out=None, hw=None) -> torch.Tensor:
+    """Chaining form of the 1x1 layer: A and/or C may be the padded [N][H+2][W+2][.] tensors of the
+    3x3 layer (flags A_PADDED / C_PADDED), a residual [M][Kout] may be added before the ReLU.
+    The feature-map size comes from the padded A, else from a 4-D unpadded A [N][H][W][Cin], else
+    from `hw`, else it is the reference's 14 x 14 (wino_conv1x1_bn_ex); anything but 14 x 14 goes
+    through wino_conv1x1_bn_ex_hw."""
     a, bm = _dev(A, "A"), _dev(B, "B")
     b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
     Cin, Kout = int(bm.shape[0]), int(bm.shape[1])
+    H = W = None
     if flags & A_PADDED:
-        if a.dim() != 4 or tuple(a.shape[1:]) != (16, 16, Cin):
-            raise WinoError("A_PADDED: A must be [N][16][16][Cin]")
-        M = int(a.shape[0]) * 196
+        if a.dim() != 4 or int(a.shape[3]) != Cin or a.shape[1] < 3 or a.shape[2] < 3:
+            raise WinoError("A_PADDED: A must be [N][H+2][W+2][Cin]")
+        H, W = int(a.shape[1]) - 2, int(a.shape[2]) - 2
+        N = int(a.shape[0])
+        M = N * H * W
     else:
+        if a.dim() == 4:
+            H, W = int(a.shape[1]), int(a.shape[2])
         a = a.reshape(-1, Cin)
         M = int(a.shape[0])
+    if hw is not None:
+        if H is not None and (H, W) != tuple(hw):
+            raise WinoError(f"hw={tuple(hw)} contradicts A's {H}x{W}")
+        H, W = int(hw[0]), int(hw[1])
+    if H is None:
+        H = W = 14
+    padded = bool(flags & (A_PADDED | C_PADDED))
+    if padded and M % (H * W):
+        raise WinoError(f"padded layouts need M = N*{H}*{W}, got M={M}")
     r = _dev(residual, "residual") if residual is not None else None
-    if flags & C_PADDED:
-        shape = (M // 196, 16, 16, Kout)
-    else:
-        shape = (M, Kout)
+    shape = (M // (H * W), H + 2, W + 2, Kout) if flags & C_PADDED else (M, Kout)
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=a.device)
-    _check(lib().wino_conv1x1_bn_ex(a.data_ptr(), bm.data_ptr(), b.data_ptr(), s.data_ptr(),
-                                    r.data_ptr() if r is not None else None, out.data_ptr(),
-                                    M, Cin, Kout, int(flags), _stream()), "wino_conv1x1_bn_ex")
+    if padded and (H, W) != (14, 14):
+        _check(lib().wino_conv1x1_bn_ex_hw(a.data_ptr(), bm.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                           r.data_ptr() if r is not None else None, out.data_ptr(),
+                                           M // (H * W), H, W, Cin, Kout, int(flags), _stream()),
+               "wino_conv1x1_bn_ex_hw")
+    else:
+        _check(lib().wino_conv1x1_bn_ex(a.data_ptr(), bm.data_ptr(), b.data_ptr(), s.data_ptr(),
+                                        r.data_ptr() if r is not None else None, out.data_ptr(),
+                                        M, Cin, Kout, int(flags), _stream()), "wino_conv1x1_bn_ex")
     return out
 
 
 def residual_block(x, w1, bn1, U2, bn2, w3, bn3, out=None, workspace=None) -> torch.Tensor:
-    """ResNet bottleneck of the 14x14 stage: x [N][14][14][C4] -> same shape.  bnX = (bias, scale)
-    folded BN vectors; w1 [C4][Cm], w3 [Cm][C4]; U2 from filter_transform_f2 (Cm -> Cm)."""
+    """ResNet bottleneck: x [N][H][W][C4] -> same shape (the reference's stage is 14 x 14:
+    wino_residual_block; other sizes: wino_residual_block_hw).  bnX = (bias, scale) folded BN
+    vectors; w1 [C4][Cm], w3 [Cm][C4]; U2 from filter_transform_f2 (Cm -> Cm)."""
     x = _dev(x, "x")
-    N, C4 = int(x.shape[0]), int(x.shape[-1])
+    if x.dim() != 4:
+        raise WinoError("x must be [N][H][W][C4]")
+    N, H, W, C4 = (int(v) for v in x.shape)
     w1, w3, U2 = _dev(w1, "w1"), _dev(w3, "w3"), _dev(U2, "U2")
     Cm = int(w1.shape[1])
     vecs = [_dev(v, "bn") for pair in (bn1, bn2, bn3) for v in pair]
-    need = lib().wino_residual_block_workspace_bytes(N, Cm)
+    need = lib().wino_residual_block_workspace_bytes_hw(N, H, W, Cm)
     if workspace is None:
         workspace = torch.empty(need // 4, dtype=torch.float32, device=x.device)
     if out is None:
         out = torch.empty_like(x)
-    _check(lib().wino_residual_block(x.data_ptr(), w1.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
-                                     U2.data_ptr(), vecs[2].data_ptr(), vecs[3].data_ptr(),
-                                     w3.data_ptr(), vecs[4].data_ptr(), vecs[5].data_ptr(),
-                                     out.data_ptr(), N, C4, Cm, workspace.data_ptr(),
-                                     workspace.numel() * 4, _stream()), "wino_residual_block")
+    args = (x.data_ptr(), w1.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
+            U2.data_ptr(), vecs[2].data_ptr(), vecs[3].data_ptr(),
+            w3.data_ptr(), vecs[4].data_ptr(), vecs[5].data_ptr(), out.data_ptr())
+    if (H, W) == (14, 14):
+        _check(lib().wino_residual_block(*args, N, C4, Cm, workspace.data_ptr(), workspace.numel() * 4, _stream()),
+               "wino_residual_block")
+    else:
+        _check(lib().wino_residual_block_hw(*args, N, H, W, C4, Cm, workspace.data_ptr(),
+                                            workspace.numel() * 4, _stream()), "wino_residual_block_hw")
     return out
 
 

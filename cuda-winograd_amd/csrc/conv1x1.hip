@@ -135,7 +135,7 @@ template <int BK, int NW>
 static int launch_1x1(const float* A, const float* B, const float* bnBias, const float* bnScale,
                       const float* R, float* C, long M, int Cin, int Kout, int flags, int nMB,
                       hipStream_t s, int batch = 1, long batchA = 0, long batchB = 0, long batchC = 0,
-                      bool prepare_only = false) {
+                      bool prepare_only = false, PadGeo pg = make_padgeo(WINO_PQ, WINO_PQ)) {
   using G = Cfg<BK, NW>;
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
@@ -156,13 +156,13 @@ static int launch_1x1(const float* A, const float* B, const float* bnBias, const
     if (int rc = sk_scratch(dev, s, (size_t)2 * Gsk * NW * RB * 1024, (size_t)tiles, &sk.slabs, &sk.tickets)) return rc;
     if (prepare_only) return WINO_OK;
     hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW, 0, true>), dim3(Gsk), dim3(G::NT), G::LDS_BYTES, s, A, B,
-                       bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, 0L, 0L, 0L, sk);
+                       bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, 0L, 0L, 0L, sk, pg);
     return launch_status("conv1x1_bn_kernel (stream-K)");
   }
   if (prepare_only) return WINO_OK;
   const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
   hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW>), dim3(grid, batch), dim3(G::NT), G::LDS_BYTES, s, A, B,
-                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC, SkArgs{nullptr, nullptr});
+                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC, SkArgs{nullptr, nullptr}, pg);
   return launch_status("conv1x1_bn_kernel");
 }
 
@@ -183,11 +183,10 @@ int gemm_batched(const float* A, const float* B, float* C, long M, int Cin, int 
 }
 }  // namespace wino
 
-extern "C" {
-
-int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, const float* bnScale,
-                       const float* residual, float* C, long M, int Cin, int Kout, int flags,
-                       wino_stream_t s) {
+// Shared body of wino_conv1x1_bn_ex (H = W = 14) and wino_conv1x1_bn_ex_hw.
+static int conv1x1_ex(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                      const float* residual, float* C, long M, int H, int W, int Cin, int Kout, int flags,
+                      wino_stream_t s) {
   if (!A || !B || !bnBias || !bnScale || !C) { set_error("NULL pointer"); return WINO_E_ARG; }
   if ((flags & WINO_ADD_RESIDUAL) && !residual) { set_error("WINO_ADD_RESIDUAL without residual"); return WINO_E_ARG; }
   if (flags & ~(WINO_RELU | WINO_A_PADDED | WINO_C_PADDED | WINO_ADD_RESIDUAL)) { set_error("unknown flag bits 0x%x", flags); return WINO_E_ARG; }
@@ -196,19 +195,42 @@ int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, cons
               M, Cin, Kout);
     return WINO_E_SHAPE;
   }
-  if ((flags & (WINO_A_PADDED | WINO_C_PADDED)) && (M % (WINO_PQ * WINO_PQ)) != 0) {
-    set_error("padded layouts need M = N*196, got M=%ld", M);
-    return WINO_E_SHAPE;
-  }
   const long nMBl = (M + BM - 1) / BM;
   if (nMBl > (1L << 24)) { set_error("M too large"); return WINO_E_SHAPE; }
   const int nMB = (int)nMBl;
+  PadGeo pg = make_padgeo(WINO_PQ, WINO_PQ);
+  if (flags & (WINO_A_PADDED | WINO_C_PADDED)) {
+    if (H < 1 || W < 1 || H > 4094 || W > 4094) { set_error("unsupported feature map %dx%d", H, W); return WINO_E_SHAPE; }
+    if ((M % ((long)H * W)) != 0) {
+      set_error("padded layouts need M = N*%d*%d, got M=%ld", H, W, M);
+      return WINO_E_SHAPE;
+    }
+    // the ring pass counts 16-byte units in 32 bits
+    const unsigned long long ring_units = (unsigned long long)(M / ((long)H * W)) * (2ull * (W + 2) + 2ull * H) * (Kout / 4);
+    if (ring_units >= (1ull << 32)) { set_error("padded output too large for one launch"); return WINO_E_SHAPE; }
+    pg = make_padgeo(H, W);
+  }
   // BK = 32 keeps a workgroup at 60 KB of LDS, so two workgroups share a CU (4 waves per SIMD)
   // and one's prologue / barrier bubbles / store tail hide under the other's MFMAs; measured
   // 3-14 % faster than BK = 64 (120 KB, one workgroup per CU) on the four reference shapes.
   if (four_waves(Cin, Kout))
-    return launch_1x1<32, 4>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s);
-  return launch_1x1<32, 8>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s);
+    return launch_1x1<32, 4>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s, 1, 0, 0, 0, false, pg);
+  return launch_1x1<32, 8>(A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, nMB, (hipStream_t)s, 1, 0, 0, 0, false, pg);
+}
+
+extern "C" {
+
+int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                       const float* residual, float* C, long M, int Cin, int Kout, int flags,
+                       wino_stream_t s) {
+  return conv1x1_ex(A, B, bnBias, bnScale, residual, C, M, WINO_PQ, WINO_PQ, Cin, Kout, flags, s);
+}
+
+int wino_conv1x1_bn_ex_hw(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                          const float* residual, float* C, int N, int H, int W, int Cin, int Kout,
+                          int flags, wino_stream_t s) {
+  if (N < 1 || H < 1 || W < 1) { set_error("bad N=%d H=%d W=%d", N, H, W); return WINO_E_SHAPE; }
+  return conv1x1_ex(A, B, bnBias, bnScale, residual, C, (long)N * H * W, H, W, Cin, Kout, flags, s);
 }
 
 // Host-side only: the launch form this shape takes on a device with `cus` compute units.
@@ -257,28 +279,41 @@ int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const f
 // 1x1 (C4 -> Cm) + BN + ReLU  ->  3x3 (Cm -> Cm) + BN + ReLU  ->  1x1 (Cm -> C4) + BN + skip + ReLU.
 // Three launches on one stream; the two intermediates live in `workspace` in the padded
 // [N][16][16][Cm] layout the 3x3 kernel reads and writes, so no repacking pass exists.
+int wino_residual_block_hw(const float* x, const float* w1, const float* bn1Bias, const float* bn1Scale,
+                           const float* U2, const float* bn2Bias, const float* bn2Scale,
+                           const float* w3, const float* bn3Bias, const float* bn3Scale, float* out,
+                           int N, int H, int W, int C4, int Cm, void* workspace, size_t workspace_bytes,
+                           wino_stream_t s) {
+  if (N < 1 || H < 1 || W < 1) { set_error("bad N=%d H=%d W=%d", N, H, W); return WINO_E_SHAPE; }
+  if (!workspace || workspace_bytes < wino_residual_block_workspace_bytes_hw(N, H, W, Cm)) {
+    set_error("workspace too small: need %zu bytes", wino_residual_block_workspace_bytes_hw(N, H, W, Cm));
+    return WINO_E_ARG;
+  }
+  float* t1 = (float*)workspace;
+  float* t2 = t1 + (size_t)N * (H + 2) * (W + 2) * Cm;
+  int rc = wino_conv1x1_bn_ex_hw(x, w1, bn1Bias, bn1Scale, NULL, t1, N, H, W, C4, Cm, WINO_RELU | WINO_C_PADDED, s);
+  if (rc) return rc;
+  rc = wino_conv3x3_bn_relu_hw(t1, U2, bn2Bias, bn2Scale, t2, N, H, W, Cm, Cm, 1, s);
+  if (rc) return rc;
+  return wino_conv1x1_bn_ex_hw(t2, w3, bn3Bias, bn3Scale, x, out, N, H, W, Cm, C4,
+                               WINO_RELU | WINO_A_PADDED | WINO_ADD_RESIDUAL, s);
+}
+
+size_t wino_residual_block_workspace_bytes_hw(int N, int H, int W, int Cm) {
+  return (size_t)2 * N * (H + 2) * (W + 2) * Cm * sizeof(float);
+}
+
 int wino_residual_block(const float* x, const float* w1, const float* bn1Bias, const float* bn1Scale,
                         const float* U2, const float* bn2Bias, const float* bn2Scale,
                         const float* w3, const float* bn3Bias, const float* bn3Scale, float* out,
                         int N, int C4, int Cm, void* workspace, size_t workspace_bytes,
                         wino_stream_t s) {
-  if (!workspace || workspace_bytes < wino_residual_block_workspace_bytes(N, Cm)) {
-    set_error("workspace too small: need %zu bytes", wino_residual_block_workspace_bytes(N, Cm));
-    return WINO_E_ARG;
-  }
-  float* t1 = (float*)workspace;
-  float* t2 = t1 + (size_t)N * WINO_HW * WINO_HW * Cm;
-  const long M = (long)N * WINO_PQ * WINO_PQ;
-  int rc = wino_conv1x1_bn_ex(x, w1, bn1Bias, bn1Scale, NULL, t1, M, C4, Cm, WINO_RELU | WINO_C_PADDED, s);
-  if (rc) return rc;
-  rc = wino_conv3x3_bn_relu(t1, U2, bn2Bias, bn2Scale, t2, N, Cm, Cm, 1, s);
-  if (rc) return rc;
-  return wino_conv1x1_bn_ex(t2, w3, bn3Bias, bn3Scale, x, out, M, Cm, C4,
-                            WINO_RELU | WINO_A_PADDED | WINO_ADD_RESIDUAL, s);
+  return wino_residual_block_hw(x, w1, bn1Bias, bn1Scale, U2, bn2Bias, bn2Scale, w3, bn3Bias, bn3Scale, out,
+                                N, WINO_PQ, WINO_PQ, C4, Cm, workspace, workspace_bytes, s);
 }
 
 size_t wino_residual_block_workspace_bytes(int N, int Cm) {
-  return (size_t)2 * N * WINO_HW * WINO_HW * Cm * sizeof(float);
+  return wino_residual_block_workspace_bytes_hw(N, WINO_PQ, WINO_PQ, Cm);
 }
 
 int wino_conv1x1_direct(const float* A, const float* B, const float* bnBias,

@@ -44,11 +44,32 @@ __device__ __forceinline__ void wait_lds1(int n) {
   }
 }
 
-// logical pixel row m = n*196 + y*14 + x  ->  row of the padded [N][16][16][.] tensor
-__device__ __forceinline__ long padded_row(long m) {
-  const long n = m / (WINO_PQ * WINO_PQ);
-  const int rem = (int)(m - n * (WINO_PQ * WINO_PQ));
-  return n * (WINO_HW * WINO_HW) + (rem / WINO_PQ + 1) * WINO_HW + rem % WINO_PQ + 1;
+// Geometry of the padded tensors a chained layer reads (WINO_A_PADDED) or writes (WINO_C_PADDED):
+// H x W feature maps inside [N][H+2][W+2][.] -- the 3x3 layer's input / output layout.  The
+// reference's stage is 14 x 14 in 16 x 16; any other size travels here.
+struct PadGeo {
+  unsigned hw, w;        // pixels per image, per row
+  unsigned Hp, Wp;       // padded extents
+  FastDiv d_hw, d_w;
+};
+__host__ inline PadGeo make_padgeo(int H, int W) {
+  PadGeo g;
+  g.hw = (unsigned)H * (unsigned)W;
+  g.w = (unsigned)W;
+  g.Hp = (unsigned)H + 2;
+  g.Wp = (unsigned)W + 2;
+  g.d_hw = make_fastdiv(g.hw);
+  g.d_w = make_fastdiv(g.w);
+  return g;
+}
+// logical pixel row m = n*H*W + y*W + x  ->  row of the padded [N][H+2][W+2][.] tensor
+__device__ __forceinline__ long padded_row(long m, const PadGeo& g) {
+  const unsigned mu = (unsigned)m;   // M < 2^31 (checked on the host)
+  const unsigned n = fastdiv(mu, g.d_hw);
+  const unsigned rem = mu - n * g.hw;
+  const unsigned y = fastdiv(rem, g.d_w);
+  const unsigned x = rem - y * g.w;
+  return (long)n * (g.Hp * g.Wp) + (long)((y + 1) * g.Wp + x + 1);
 }
 
 template <int BK, int NW>
@@ -100,7 +121,7 @@ __global__ void __launch_bounds__(64 * NW, 2)
 conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                   const float* __restrict__ bnBias, const float* __restrict__ bnScale,
                   const float* __restrict__ R, float* __restrict__ Cout, long M, int Cin, int Kout,
-                  int flags, int nMB, long batchA, long batchB, long batchC, SkArgs sk = SkArgs{nullptr, nullptr}) {
+                  int flags, int nMB, long batchA, long batchB, long batchC, SkArgs sk, PadGeo pg) {
   using G = Cfg<BK, NW>;
   // batched GEMMs (the 36 Winograd points of the F(4x4) compatibility path): blockIdx.y selects
   // the problem, the three operands advance by their batch strides (in floats)
@@ -118,18 +139,20 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (c_padded && !(ABLATE & 512)) {
     // ring pass: the padded output's zero ring (the 3x3 layer's padding) as a flat list of
-    // 16-byte units -- M/196 images x 60 ring pixels x Kout/4 units -- split over the grid
+    // 16-byte units -- images x ring pixels x Kout/4 units -- split over the grid
     const unsigned upp = (unsigned)Kout >> 2;
-    const unsigned long long U = (unsigned long long)(M / (WINO_PQ * WINO_PQ)) * 60u * upp;
+    const unsigned rpx = 2 * pg.Wp + 2 * (pg.Hp - 2);   // ring pixels per image
+    const unsigned imgs = fastdiv((unsigned)M, pg.d_hw);
+    const unsigned long long U = (unsigned long long)imgs * rpx * upp;
     const unsigned u_begin = (unsigned)(U * bid / gridDim.x), u_end = (unsigned)(U * (bid + 1ull) / gridDim.x);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     for (unsigned u = u_begin + threadIdx.x; u < u_end; u += 64 * NW) {
       const unsigned pid = u / upp, unit = u - pid * upp;
-      const unsigned n = pid / 60u, q = pid - n * 60u;
-      // q: 0..15 row 0, 16..31 row 15, 32..45 column 0 (rows 1..14), 46..59 column 15
-      const unsigned y = q < 16 ? 0u : q < 32 ? (unsigned)(WINO_HW - 1) : q < 46 ? q - 31u : q - 45u;
-      const unsigned x = q < 16 ? q : q < 32 ? q - 16u : q < 46 ? 0u : (unsigned)(WINO_HW - 1);
-      *(f32x4*)(Cout + ((size_t)(n * WINO_HW + y) * WINO_HW + x) * Kout + unit * 4) = zero4;
+      const unsigned n = pid / rpx, q = pid - n * rpx;
+      // q: [0, Wp) row 0, [Wp, 2Wp) the last row, then column 0 and the last column of rows 1..Hp-2
+      const unsigned y = q < pg.Wp ? 0u : q < 2 * pg.Wp ? pg.Hp - 1 : q < 2 * pg.Wp + pg.Hp - 2 ? q - 2 * pg.Wp + 1 : q - 2 * pg.Wp - (pg.Hp - 2) + 1;
+      const unsigned x = q < pg.Wp ? q : q < 2 * pg.Wp ? q - pg.Wp : q < 2 * pg.Wp + pg.Hp - 2 ? 0u : pg.Wp - 1;
+      *(f32x4*)(Cout + ((size_t)(n * pg.Hp + y) * pg.Wp + x) * Kout + unit * 4) = zero4;
     }
   }
   // The work of this workgroup: [u, uend) in the space (row tile mb) * nk + k-step, for ONE column
@@ -187,7 +210,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     const int unit = (lane % G::UNITS) ^ G::fa(row);
     long gr = m0 + row;
     gr = gr < M ? gr : M - 1;  // clamp: padded rows (and pieces past the tile) read a valid row
-    if (a_padded) gr = padded_row(gr);
+    if (a_padded) gr = padded_row(gr, pg);
     a_src[j] = A + gr * Cin + unit * 4;
   }
   // B piece q covers B_ROWS_PER_PIECE k rows; lane -> (k, unit'); source unit = unit' ^ 4*bit2(k)
@@ -380,9 +403,9 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
             for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
           }
         }
-        // c_padded: row = pixel (n, py-1, px-1) of the 14x14 map -> interior of [N][16][16][Kout]
+        // c_padded: row = pixel (n, y, x) of the H x W map -> interior of [N][H+2][W+2][Kout]
         // (its zero ring is written by the ring pass at the top of the kernel)
-        const long orow = c_padded ? padded_row(grow) : grow;
+        const long orow = c_padded ? padded_row(grow, pg) : grow;
         *(f32x4*)(Cout + orow * Kout + n0 + c4) = val;
       }
     }

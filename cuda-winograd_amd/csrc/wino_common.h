@@ -82,6 +82,26 @@ __device__ inline void buf_store16(f32x4, buffer_rsrc_t, unsigned, unsigned) {}
 __device__ inline f32x4 slab_load16(buffer_rsrc_t, unsigned, unsigned) { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 #endif
 
+// Division of a 32-bit unsigned by a launch-invariant divisor (Granlund-Montgomery): the
+// multiplier travels in the kernel arguments, q = (t + ((n - t) >> 1)) >> (l - 1), t = umulhi(m, n).
+struct FastDiv {
+  unsigned m, l;   // l = 0: divisor 1
+};
+__host__ __device__ inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f = {0u, 0u};
+  if (d <= 1) return f;
+  unsigned l = 0;
+  while ((1ull << l) < d) l++;
+  f.l = l;
+  f.m = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1ull);
+  return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) {
+  if (f.l == 0) return n;
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> 1)) >> (f.l - 1);
+}
+
 __device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 }  // namespace wino

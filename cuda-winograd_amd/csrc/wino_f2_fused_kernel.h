@@ -108,24 +108,7 @@ __device__ __forceinline__ TileCoord decode_tile(int g) {
 // padded (H+2) x (W+2) tensors.  The reference's 14x14 stage is a compile-time specialisation
 // (GEN = false: the divisions by 49 and 7 fold into multiplies); other sizes (ResNet's 56x56 and
 // 28x28 stages) carry the numbers in the kernel arguments, with the two
-// divisors as Granlund-Montgomery multipliers: q = (t + ((n - t) >> 1)) >> (l - 1), t = umulhi(m, n).
-struct FastDiv {
-  unsigned m, l;   // l = 0: divisor 1
-};
-__host__ __device__ inline FastDiv make_fastdiv(unsigned d) {
-  FastDiv f = {0u, 0u};
-  if (d <= 1) return f;
-  unsigned l = 0;
-  while ((1ull << l) < d) l++;
-  f.l = l;
-  f.m = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1ull);
-  return f;
-}
-__device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) {
-  if (f.l == 0) return n;
-  const unsigned t = __umulhi(f.m, n);
-  return (t + ((n - t) >> 1)) >> (f.l - 1);
-}
+// divisors as Granlund-Montgomery multipliers (FastDiv, wino_common.h).
 struct Geo {
   int Hp, Wp;              // padded extents
   unsigned tiles, tiles_x;  // tiles per image, per tile row

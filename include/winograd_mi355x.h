@@ -177,6 +177,13 @@ int wino_conv1x1_bn(const float* A, const float* B, const float* bnBias, const f
 int wino_conv1x1_bn_ex(const float* A, const float* B, const float* bnBias, const float* bnScale,
                        const float* residual, float* C, long M, int Cin, int Kout, int flags,
                        wino_stream_t s);
+/* The same for any feature-map size: A [N*H*W][Cin] or, with WINO_A_PADDED,
+ * [N][H+2][W+2][Cin]; C [N*H*W][Kout] or, with WINO_C_PADDED, [N][H+2][W+2][Kout] with its ring
+ * written as 0 -- the layouts wino_conv3x3_bn_relu_hw reads and writes.  H = W = 14 is exactly
+ * wino_conv1x1_bn_ex with M = N*196. */
+int wino_conv1x1_bn_ex_hw(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                          const float* residual, float* C, int N, int H, int W, int Cin, int Kout,
+                          int flags, wino_stream_t s);
 /* Shapes whose tile count leaves the last round of workgroups mostly empty (the reference's
  * 512->128 and 1024->256 layers at N = 128: 448 tiles on 256 CUs) are launched in stream-K form
  * and use library-owned scratch of stream `s`, allocated on the first such launch.  Call this
@@ -204,6 +211,14 @@ int wino_residual_block(const float* x, const float* w1, const float* bn1Bias, c
                         const float* w3, const float* bn3Bias, const float* bn3Scale, float* out,
                         int N, int C4, int Cm, void* workspace, size_t workspace_bytes,
                         wino_stream_t s);
+/* The block at any feature-map size (ResNet's 56x56 / 28x28 / 7x7 stages):
+ * x, out [N][H][W][C4].  H = W = 14 is exactly wino_residual_block. */
+size_t wino_residual_block_workspace_bytes_hw(int N, int H, int W, int Cm);
+int wino_residual_block_hw(const float* x, const float* w1, const float* bn1Bias, const float* bn1Scale,
+                           const float* U2, const float* bn2Bias, const float* bn2Scale,
+                           const float* w3, const float* bn3Bias, const float* bn3Scale, float* out,
+                           int N, int H, int W, int C4, int Cm, void* workspace, size_t workspace_bytes,
+                           wino_stream_t s);
 
 /* Independent comparator for the 1x1 layers: one thread per output, fp32 FMA loop. */
 int wino_conv1x1_direct(const float* A, const float* B, const float* bnBias,

@@ -208,18 +208,18 @@ def conv1x1_bn(A, B, bn_bias, bn_scale, relu, dtype=np.float64):
 
 
 def residual_block(x, w1, bn1, w2_kcrs, bn2, w3, bn3, dtype=np.float64):
-    """ResNet bottleneck of the 14x14 stage as the composition of the three layer oracles
-    (not in the reference, SURVEY.md D5 / section 8f): x [N][14][14][C4];
+    """ResNet bottleneck as the composition of the three layer oracles (not in the reference,
+    SURVEY.md D5 / section 8f): x [N][h][w][C4] (the reference's stage is 14 x 14);
     1x1 C4->Cm +BN+ReLU, 3x3 Cm->Cm (zero padding 1) +BN+ReLU, 1x1 Cm->C4 +BN, + x, ReLU.
     bnX = (bias, scale) folded."""
     x = np.asarray(x, dtype)
-    N, _, _, C4 = x.shape
+    N, h, w, C4 = x.shape
     Cm = np.asarray(w1).shape[1]
-    t1 = conv1x1_bn(x.reshape(-1, C4), w1, bn1[0], bn1[1], True, dtype).reshape(N, P, Q, Cm)
-    t1p = np.zeros((N, H, W, Cm), dtype)
-    t1p[:, 1:15, 1:15, :] = t1
-    t2 = conv3x3_bn_relu_direct(t1p, w2_kcrs, bn2[1], bn2[0], True, dtype)[:, 1:15, 1:15, :]
-    t3 = conv1x1_bn(t2.reshape(-1, Cm), w3, bn3[0], bn3[1], False, dtype).reshape(N, P, Q, C4)
+    t1 = conv1x1_bn(x.reshape(-1, C4), w1, bn1[0], bn1[1], True, dtype).reshape(N, h, w, Cm)
+    t1p = np.zeros((N, h + 2, w + 2, Cm), dtype)
+    t1p[:, 1:-1, 1:-1, :] = t1
+    t2 = conv3x3_bn_relu_direct(t1p, w2_kcrs, bn2[1], bn2[0], True, dtype)[:, 1:-1, 1:-1, :]
+    t3 = conv1x1_bn(t2.reshape(-1, Cm), w3, bn3[0], bn3[1], False, dtype).reshape(N, h, w, C4)
     return np.maximum(t3 + x, 0)
 
 

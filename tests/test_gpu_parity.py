@@ -521,6 +521,60 @@ def test_conv1x1_padded_in_out_and_residual(pkg, O, torch_dev):
     assert O.rel_error(got3, want3) < TIGHT
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Kout", [(2, 28, 28, 64, 128), (1, 56, 56, 64, 64), (3, 7, 7, 512, 128), (2, 5, 9, 96, 192), (4, 1, 1, 32, 64)])
+def test_conv1x1_padded_other_feature_maps(N, H, W, Cin, Kout, pkg, O, torch_dev):
+    """the chaining layouts at any feature-map size (the reference's stage is
+    14 x 14).  C_PADDED into a NaN-filled [N][H+2][W+2][Kout] (interior against the oracle, ring exact
+    zeros), A_PADDED from a tensor whose ring holds garbage, residual added before the ReLU."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(H * 100 + W)
+    A = (rng.rand(N, H, W, Cin) - 0.5).astype(np.float32)
+    B = (rng.rand(Cin, Kout) - 0.5).astype(np.float32)
+    s = (rng.rand(Kout) - 0.5).astype(np.float32)
+    b = (rng.rand(Kout) - 0.5).astype(np.float32)
+    R = (rng.rand(N * H * W, Kout) - 0.5).astype(np.float32)
+    t = lambda a: _t(torch_dev, a)
+    want = O.conv1x1_bn(A.reshape(-1, Cin), B, b, s, True)
+    out = torch.full((N, H + 2, W + 2, Kout), float("nan"), device=dev)
+    pkg.conv1x1_bn_ex(t(A), t(B), t(b), t(s), pkg.RELU | pkg.C_PADDED, out=out)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert O.rel_error(got[:, 1:-1, 1:-1, :].reshape(-1, Kout), want) < TIGHT
+    ring = np.ones((H + 2, W + 2), bool)
+    ring[1:-1, 1:-1] = False
+    assert (got[:, ring, :] == 0).all()
+    Ap = rng.rand(N, H + 2, W + 2, Cin).astype(np.float32) * 100
+    Ap[:, 1:-1, 1:-1, :] = A
+    got2 = pkg.conv1x1_bn_ex(t(Ap), t(B), t(b), t(s), pkg.RELU | pkg.A_PADDED).cpu().numpy()
+    assert got2.shape == (N * H * W, Kout)
+    assert O.rel_error(got2, want) < TIGHT
+    want3 = np.maximum(O.conv1x1_bn(A.reshape(-1, Cin), B, b, s, False) + R, 0)
+    got3 = pkg.conv1x1_bn_ex(t(Ap), t(B), t(b), t(s), pkg.RELU | pkg.A_PADDED | pkg.ADD_RESIDUAL,
+                             residual=t(R)).cpu().numpy()
+    assert O.rel_error(got3, want3) < TIGHT
+
+
+@pytest.mark.parametrize("N,H,W,C4,Cm", [(2, 28, 28, 512, 128), (1, 56, 56, 256, 64), (3, 7, 7, 2048, 512), (2, 9, 5, 256, 64)])
+def test_residual_block_other_feature_maps(N, H, W, C4, Cm, pkg, O, torch_dev):
+    """The bottleneck block at ResNet's other stages (56x56x256/64, 28x28x512/128, 7x7x2048/512) and
+    an odd size: three launches chained through padded [N][H+2][W+2][Cm] intermediates, against the
+    fp64 composition of the layer oracles."""
+    rng = np.random.RandomState(H + 7 * W)
+    x = (rng.rand(N, H, W, C4) - 0.5).astype(np.float32)
+    w1 = ((rng.rand(C4, Cm) - 0.5) / np.sqrt(C4) * 4).astype(np.float32)
+    w2 = ((rng.rand(Cm, Cm, 3, 3) - 0.5) / np.sqrt(9 * Cm) * 4).astype(np.float32)
+    w3 = ((rng.rand(Cm, C4) - 0.5) / np.sqrt(Cm) * 4).astype(np.float32)
+    bn = [((rng.rand(c) - 0.5).astype(np.float32), (rng.rand(c) + 0.5).astype(np.float32)) for c in (Cm, Cm, C4)]
+    want = O.residual_block(x, w1, bn[0], w2, bn[1], w3, bn[2])
+    t = lambda a: _t(torch_dev, a)
+    U2 = pkg.filter_transform_f2(t(w2))
+    got = pkg.residual_block(t(x), t(w1), (t(bn[0][0]), t(bn[0][1])), U2, (t(bn[1][0]), t(bn[1][1])),
+                             t(w3), (t(bn[2][0]), t(bn[2][1]))).cpu().numpy()
+    assert got.shape == want.shape
+    assert O.rel_error(got, want) < TIGHT
+    assert (want > 0).mean() > 0.2
+
+
 @pytest.mark.parametrize("N,C4,Cm", [(2, 256, 128), (5, 1024, 256), (3, 384, 192)])
 def test_residual_block(N, C4, Cm, pkg, O, torch_dev):
     """BASELINE configs[4]: 1x1 -> 3x3 -> 1x1 + skip, against the fp64 composition of the layer

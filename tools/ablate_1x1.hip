@@ -17,7 +17,7 @@ float run(const float* A, const float* B, const float* b, const float* s, float*
   const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  auto launch = [&] { hipLaunchKernelGGL((conv1x1_bn_kernel<32, NW, AB>), dim3(grid), dim3(G::NT), G::LDS_BYTES, 0, A, B, b, s, (const float*)nullptr, C, M, Cin, Kout, 1, nMB, 0L, 0L, 0L); };
+  auto launch = [&] { hipLaunchKernelGGL((conv1x1_bn_kernel<32, NW, AB>), dim3(grid), dim3(G::NT), G::LDS_BYTES, 0, A, B, b, s, (const float*)nullptr, C, M, Cin, Kout, 1, nMB, 0L, 0L, 0L, wino::gemm1x1::SkArgs{nullptr, nullptr}, wino::gemm1x1::make_padgeo(14, 14)); };
   for (int i = 0; i < 5; i++) launch();
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
