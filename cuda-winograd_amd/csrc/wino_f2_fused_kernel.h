@@ -410,7 +410,9 @@ wino_f2_fused_kernel(const FusedParams prm) {
   for (int j = 0; j < 4; j++) issue_raw1(0, j);
 #pragma unroll
   for (int j = 0; j < 4; j++) issue_u1(0, j);
-  dma_advance();
+  // The DMA walker never leaves this workgroup's range: it stops on the last chunk, and the
+  // last two iterations of the range fetch that chunk again into stages nobody reads (see body()).
+  if (L > 1) dma_advance();
   ring_pass();   // in the shadow of the first pieces' flight
   if (!(ABLATE & 8)) {
     wait_vmem_all();
@@ -421,7 +423,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
     for (int j = 0; j < 4; j++) issue_raw1(1, j);
 #pragma unroll
     for (int j = 0; j < 4; j++) issue_u1(1, j);
-    dma_advance();
+    if (L > 2) dma_advance();
   }
   {
     P2 d[16];
@@ -463,7 +465,12 @@ wino_f2_fused_kernel(const FusedParams prm) {
     // burst here: an LDS-DMA instruction holds the wave's issue port for >100 cycles, and
     // spread out the SIMD's other wave covers that with its MFMAs; starting at step 4 leaves the
     // last pieces a third of an iteration of flight time before the next vmcnt(0).
-    const bool dma_on = it + 2 < L;
+    // They are issued unconditionally: a branch per piece (the compiler routes half of the
+    // conditions through a VALU compare) cost ~30 of the ~210 instructions between an iteration's
+    // first and last MFMA.  In the last two iterations of the range, where nothing is left to
+    // fetch, the walker stands on the range's last chunk (valid addresses) and the pieces land in
+    // R[it&1] / U[(it+2)%3] like any others: free stages, disjoint from the ones an epilogue
+    // stages its stores in, and drained by the next iteration's vmcnt(0) or by the one before exit.
     const char* rst = smem;   // raw_{it+1}: the stage is in a_lo[]
     const char* ucur0 = smem + b_base[0] + us_cur * U_BYTES;   // U_it
     const char* ucur1 = smem + b_base[1] + us_cur * U_BYTES;
@@ -491,9 +498,9 @@ wino_f2_fused_kernel(const FusedParams prm) {
         bfn[e + PF - 16][1] = *(const f32x2*)(unxt1 + (e + PF - 16) * 2048);
       }
       if (e >= DMA0 && e < DMA0 + 4) {
-        if (dma_on) issue_raw1(rs_dma, e - DMA0);
+        issue_raw1(rs_dma, e - DMA0);
       } else if (e >= DMA0 + 4 && e < DMA0 + 8) {
-        if (dma_on) issue_u1(us_dma, e - DMA0 - 4);
+        issue_u1(us_dma, e - DMA0 - 4);
       }
       // next iteration's A operand rides along: steps 0-7 read its patch (two pixels of patch
       // column e>>1 per step); B^T d B itself is written below, after the step's MFMAs, and is
@@ -772,7 +779,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
         body(it, it & 1, us, next(us), next(next(us)));
 #pragma unroll
         for (int p = 0; p < 8; p++) a_lo[p] ^= RAW_BYTES;
-        if (it + 2 < L) dma_advance();
+        if (it + 3 < L) dma_advance();
         us_last = us;
         us = next(us);
         it++;
@@ -790,6 +797,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
     }
   }
 #undef A_OFF
+  wait_vmem_all();   // no LDS-DMA of this wave may land after the workgroup's LDS has been given away
 
   // diagnostic builds: stamps go past the N images of `out` (the tool allocates that room)
   if (ABLATE & 2048) {
