@@ -57,6 +57,12 @@ using namespace wino;
 // (few k-steps per workgroup: 128->512 measured 35.1 vs 37.1 us; otherwise equal to 8 waves within
 // 1 %); and whenever Kout is not a multiple of 128 -- the API takes any multiple of 64, and a
 // 128-column block would leave the last 64 columns uncomputed.
+// Cin % 32 (the k-step), Kout % 64 (the narrowest column block); B is addressed through one buffer
+// descriptor (32-bit byte offsets)
+static inline bool bad_1x1_dims(int Cin, int Kout) {
+  return Cin <= 0 || Kout <= 0 || (Cin % 32) != 0 || (Kout % 64) != 0 ||
+         (unsigned long long)Cin * (unsigned long long)Kout * sizeof(float) >= (1ull << 32);
+}
 static inline bool four_waves(int Cin, int Kout) { return Kout <= 128 || Cin <= 128 || (Kout % 128) != 0; }
 
 // Stream-K grid for `tiles` output tiles of nk k-steps on `cus` CUs, or 0 for the plain
@@ -170,7 +176,7 @@ namespace wino {
 // Batched plain GEMM C_b = A_b . B_b (no BN) on the 1x1 kernel: used by the F(4x4) compatibility path.
 int gemm_batched(const float* A, const float* B, float* C, long M, int Cin, int Kout, int batch,
                  long batchA, long batchB, long batchC, hipStream_t s) {
-  if ((Cin % 32) != 0 || (Kout % 64) != 0 || M < 1 || batch < 1 || batch > 65535) {
+  if (bad_1x1_dims(Cin, Kout) || M < 1 || batch < 1 || batch > 65535) {
     set_error("unsupported batched GEMM shape");
     return WINO_E_SHAPE;
   }
@@ -190,7 +196,7 @@ static int conv1x1_ex(const float* A, const float* B, const float* bnBias, const
   if (!A || !B || !bnBias || !bnScale || !C) { set_error("NULL pointer"); return WINO_E_ARG; }
   if ((flags & WINO_ADD_RESIDUAL) && !residual) { set_error("WINO_ADD_RESIDUAL without residual"); return WINO_E_ARG; }
   if (flags & ~(WINO_RELU | WINO_A_PADDED | WINO_C_PADDED | WINO_ADD_RESIDUAL)) { set_error("unknown flag bits 0x%x", flags); return WINO_E_ARG; }
-  if (M < 1 || Cin <= 0 || Kout <= 0 || (Cin % 32) != 0 || (Kout % 64) != 0) {
+  if (M < 1 || bad_1x1_dims(Cin, Kout)) {
     set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% 64 == 0)",
               M, Cin, Kout);
     return WINO_E_SHAPE;
@@ -237,7 +243,7 @@ int wino_conv1x1_bn_ex_hw(const float* A, const float* B, const float* bnBias, c
 int wino_conv1x1_plan(long M, int Cin, int Kout, int cus, int* grid, int* row_tiles, int* col_blocks,
                       int* k_steps, int* stream_k) {
   if (!grid || !row_tiles || !col_blocks || !k_steps || !stream_k || cus < 1) { set_error("bad argument"); return WINO_E_ARG; }
-  if (M < 1 || Cin <= 0 || Kout <= 0 || (Cin % 32) != 0 || (Kout % 64) != 0) {
+  if (M < 1 || bad_1x1_dims(Cin, Kout)) {
     set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% 64 == 0)",
               M, Cin, Kout);
     return WINO_E_SHAPE;
@@ -258,7 +264,7 @@ int wino_conv1x1_plan(long M, int Cin, int Kout, int cus, int* grid, int* row_ti
 // Allocates the stream-K scratch this shape's launches on stream `s` will use (nothing for shapes
 // that take the plain form): call it before capturing wino_conv1x1_bn(_ex) into a HIP graph.
 int wino_conv1x1_prepare(long M, int Cin, int Kout, wino_stream_t s) {
-  if (M < 1 || Cin <= 0 || Kout <= 0 || (Cin % 32) != 0 || (Kout % 64) != 0) {
+  if (M < 1 || bad_1x1_dims(Cin, Kout)) {
     set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% 64 == 0)",
               M, Cin, Kout);
     return WINO_E_SHAPE;

@@ -116,8 +116,11 @@ struct SkArgs {
   unsigned* tickets;
 };
 
+// Resident waves per SIMD the LDS footprint allows -- two 8-wave workgroups (60 KB each) or three
+// 4-wave ones (44 KB) per CU -- stated to the register allocator, which otherwise takes the
+// freedom of 256 VGPRs and halves the residency (tests/test_build_budget.py).
 template <int BK, int NW, int ABLATE = 0, bool SK = false>
-__global__ void __launch_bounds__(64 * NW, 2)
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3)
 conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                   const float* __restrict__ bnBias, const float* __restrict__ bnScale,
                   const float* __restrict__ R, float* __restrict__ Cout, long M, int Cin, int Kout,
@@ -200,36 +203,53 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   first_seg = false;
 
   // ---- DMA sources --------------------------------------------------------------
-  // A piece q covers rows q*RPP .. q*RPP+RPP-1 (RPP = 16 at BK 32... 1 KiB / row bytes);
-  // lane -> (row, unit'); source unit = unit' ^ f(row).  Wave w issues pieces w, w+8, ...
-  const float* a_src[G::A_PER_WAVE];
+  // LDS-DMA through buffer descriptors, as in the fused 3x3 kernel: per-lane byte offsets that
+  // are computed once per tile plus ONE scalar k offset per operand and iteration, instead of a
+  // 64-bit per-lane address add, a scalar multiply and a branch around every piece (those were
+  // ~9 instructions per piece, 72-108 of the ~300 in a pair of stages).
+  //   A: the descriptor starts at the tile's first row, so A itself may exceed 4 GiB.  Piece q
+  //      covers rows q*RPP .. (RPP = 1 KiB / row bytes); lane -> (row, unit'), source unit =
+  //      unit' ^ f(row).  Wave w issues pieces w, w+NW, ...; the two pieces past the tile's 14
+  //      repeat piece 13 (same bytes to the same LDS address) rather than cost a branch.
+  //      Rows past M read row M-1 (never stored).  a_padded: rows map into the padded tensor,
+  //      which only grows the window by the ring pixels in between.
+  //   B: one descriptor over all of B (< 4 GiB, checked on the host); piece q covers
+  //      B_ROWS_PER_PIECE k rows; lane -> (k, unit'), source unit = unit' ^ 4*bit2(k).
+  const long a_row0 = a_padded ? padded_row(m0 < M ? m0 : M - 1, pg) : (m0 < M ? m0 : M - 1);
+  const long m_last = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
+  const long a_rows = (a_padded ? padded_row(m_last, pg) : m_last) - a_row0 + 1;
+  const auto rsrc_a = make_rsrc(A + a_row0 * Cin, (unsigned)(a_rows * Cin * (long)sizeof(float)));
+  const auto rsrc_b = make_rsrc(B, (unsigned)((size_t)Cin * Kout * sizeof(float)));
+  unsigned a_voff[G::A_PER_WAVE];
+  int a_q[G::A_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < G::A_PER_WAVE; j++) {
-    const int q = w + NW * j;
+    int q = w + NW * j;
+    q = q < G::A_PIECES ? q : G::A_PIECES - 1;
+    a_q[j] = q;
     const int row = q * G::ROWS_PER_PIECE + lane / G::UNITS;
     const int unit = (lane % G::UNITS) ^ G::fa(row);
     long gr = m0 + row;
-    gr = gr < M ? gr : M - 1;  // clamp: padded rows (and pieces past the tile) read a valid row
+    gr = gr < M ? gr : M - 1;  // clamp: rows past the end read a valid row
     if (a_padded) gr = padded_row(gr, pg);
-    a_src[j] = A + gr * Cin + unit * 4;
+    a_voff[j] = (unsigned)((gr - a_row0) * Cin + unit * 4) * (unsigned)sizeof(float);
   }
-  // B piece q covers B_ROWS_PER_PIECE k rows; lane -> (k, unit'); source unit = unit' ^ 4*bit2(k)
-  const float* b_src[G::B_PER_WAVE];
+  unsigned b_voff[G::B_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < G::B_PER_WAVE; j++) {
     const int q = w + NW * j;
     const int k = G::B_ROWS_PER_PIECE * q + lane / G::B_UNITS;
     const int unit = (lane % G::B_UNITS) ^ (((k >> 2) & 1) << 2);
-    b_src[j] = B + (size_t)k * Kout + n0 + unit * 4;
+    b_voff[j] = (unsigned)(k * Kout + n0 + unit * 4) * (unsigned)sizeof(float);
   }
-  auto issue_piece = [&](int stage, int kc, int p) {  // p = 0 .. A_PER_WAVE + B_PER_WAVE - 1
+  const unsigned a_kstep = (unsigned)(BK * sizeof(float)), b_kstep = (unsigned)(BK * sizeof(float)) * (unsigned)Kout;
+  auto issue_piece = [&](int stage, unsigned a_soff, unsigned b_soff, int p) {  // p = 0 .. A_PER_WAVE + B_PER_WAVE - 1
     char* sb = smem + stage * G::STAGE;
     if (p < G::A_PER_WAVE) {
-      const int q = w + NW * p;
-      if (q < G::A_PIECES && !(ABLATE & 1)) dma16(a_src[p] + kc * BK, sb + q * 1024);
+      if (!(ABLATE & 1)) dma16_buf(rsrc_a, a_voff[p], a_soff, sb + a_q[p] * 1024);
     } else {
       const int j = p - G::A_PER_WAVE, q = w + NW * j;
-      if (!(ABLATE & 2)) dma16(b_src[j] + (size_t)kc * BK * Kout, sb + G::A_BYTES + q * 1024);
+      if (!(ABLATE & 2)) dma16_buf(rsrc_b, b_voff[j], b_soff, sb + G::A_BYTES + q * 1024);
     }
   };
   constexpr int PIECES = G::A_PER_WAVE + G::B_PER_WAVE;
@@ -248,15 +268,19 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   for (int i = 0; i < RB; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-  for (int p = 0; p < PIECES; p++) issue_piece(0, k0, p);
+  for (int p = 0; p < PIECES; p++) issue_piece(0, (unsigned)k0 * a_kstep, (unsigned)k0 * b_kstep, p);
 
-  auto body = [&](auto par, int it) {
+  // `more` (is there a k-step after this one to fetch) is a compile-time property of the body: the
+  // last iteration of a segment is peeled below, so no piece is issued behind a branch
+  auto body = [&](auto par, auto more_c, int it) {
     constexpr int PAR = decltype(par)::value;
+    constexpr bool more = decltype(more_c)::value;
     if (!(ABLATE & 8)) {
       wait_vmem_all();
       __syncthreads();
     }
-    const bool more = it + 1 < len;   // `it` counts from the segment's first k-step k0
+    const unsigned a_soff = (unsigned)(k0 + it + 1) * a_kstep;   // `it` counts from the segment's first k-step k0
+    const unsigned b_soff = (unsigned)(k0 + it + 1) * b_kstep;
     const char* st = smem + PAR * G::STAGE;
     f32x4 a[G::T];
     float b[G::S][4];
@@ -278,7 +302,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       }
       // this wave's LDS-DMA pieces for the next stage, one per step from step 4 on
       if (t >= 4 && t - 4 < PIECES) {
-        if (more) issue_piece(PAR ^ 1, k0 + it + 1, t - 4);
+        if (more) issue_piece(PAR ^ 1, a_soff, b_soff, t - 4);
       }
       __builtin_amdgcn_sched_barrier(0);
       wait_lds1(G::wait_count(t));
@@ -291,10 +315,21 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int it = 0;
 #pragma unroll 1
-  for (int it = 0; it < len; it += 2) {
-    body(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < len) body(std::integral_constant<int, 1>{}, it + 1);
+    for (; it + 2 < len; it += 2) {
+      body(P0{}, std::true_type{}, it);
+      body(P1{}, std::true_type{}, it + 1);
+    }
+    if (it + 2 == len) {
+      body(P0{}, std::true_type{}, it);
+      body(P1{}, std::false_type{}, it + 1);
+    } else {
+      body(P0{}, std::false_type{}, it);
+    }
   }
 
   // ---- epilogue: BN (+residual) (+ReLU).  C/D layout: col = lane&15, row = 4*(lane>>4)+i.
