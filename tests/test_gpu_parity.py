@@ -490,6 +490,35 @@ def test_one_by_one_streamk_flags_and_graph(pkg, O, torch_dev, monkeypatch):
         assert O.rel_error(outg.cpu().numpy(), want) < TIGHT
 
 
+def test_one_by_one_activations_beyond_4gib(pkg, O, torch_dev):
+    """The 1x1 kernel addresses A through a buffer descriptor (32-bit byte offsets) that is re-based
+    at every tile's first row, so A itself may be larger than 4 GiB: 1.1 M rows x 1024 channels =
+    4.5 GB here.  Rows on both sides of the 4 GiB boundary (row 2^32 / 4096 = 1 048 576), the first
+    and the last tile against the fp64 oracle; every output finite."""
+    torch, dev = torch_dev
+    M, Cin, Kout = 1_100_000, 1024, 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < 8 * (1 << 30):
+        pytest.skip("needs 8 GiB of free device memory")
+    g = torch.Generator(device=dev).manual_seed(4)
+    A = torch.rand(M, Cin, device=dev, generator=g) - 0.5
+    rng = np.random.RandomState(4)
+    B = (rng.rand(Cin, Kout) - 0.5).astype(np.float32)
+    s = (rng.rand(Kout) - 0.5).astype(np.float32)
+    b = (rng.rand(Kout) - 0.5).astype(np.float32)
+    out = torch.full((M, Kout), float("nan"), device=dev)
+    pkg.conv1x1_bn(A, _t(torch_dev, B), _t(torch_dev, b), _t(torch_dev, s), False, out=out)
+    assert bool(torch.isfinite(out).all())
+    boundary = (1 << 32) // (Cin * 4)
+    rows = np.unique(np.concatenate([np.arange(0, 224), np.arange(boundary - 300, boundary + 300),
+                                     np.arange(M - 224, M), rng.randint(0, M, 500)]))
+    idx = torch.as_tensor(rows, device=dev)
+    want = O.conv1x1_bn(A[idx].cpu().numpy(), B, b, s, False)
+    assert O.rel_error(out[idx].cpu().numpy(), want) < TIGHT
+    del A, out
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------ chaining (SURVEY 8f)
 def test_conv1x1_padded_in_out_and_residual(pkg, O, torch_dev):
     torch, dev = torch_dev
