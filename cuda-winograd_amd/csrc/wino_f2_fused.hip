@@ -222,21 +222,40 @@ static int sk_grid_for(int cus, long long items, int nchunks, int* G) {
   return WINO_OK;
 }
 
-static int check_conv3x3(int N, int H, int W, int C, int K) {
+// The largest batch one launch takes: the kernels address the tensors with 32-bit byte offsets
+// (both tensors must stay below 4 GiB) and the stream-K bookkeeping counts chunk iterations in
+// 32 bits.  Larger batches are split by the launcher (images are independent).
+static long long conv3x3_batch_limit(int H, int W, int C, int K) {
+  const unsigned long long per_image = (unsigned long long)(H + 2) * (W + 2) * (unsigned long long)(C > K ? C : K) * sizeof(float);
+  long long n = (long long)(((1ull << 32) - 1) / per_image);
+  const long long tiles = (long long)((H + 1) / 2) * ((W + 1) / 2);
+  const long long per_tb = (long long)(K / KB) * (C / BC);               // chunk iterations per 64-tile block
+  const long long max_tb = ((1ll << 31) - 1) / per_tb - 1;
+  const long long n_iter = max_tb * TB / tiles;
+  if (n > n_iter) n = n_iter;
+  if (n > (1ll << 30)) n = 1ll << 30;
+  return n;
+}
+
+static int check_conv3x3_dims(int H, int W, int C, int K) {
   if (int rc = check_ck(C, K)) return rc;
   if (H < 1 || W < 1 || H > 4094 || W > 4094) {
     set_error("unsupported feature map %dx%d", H, W);
     return WINO_E_SHAPE;
   }
-  // the kernels address the tensors with 32-bit byte offsets
-  if (N < 1 || (size_t)N * (H + 2) * (W + 2) * (size_t)(C > K ? C : K) * sizeof(float) >= (1ull << 32)) {
-    set_error("bad batch N=%d (input/output must stay below 4 GiB)", N);
+  if (conv3x3_batch_limit(H, W, C, K) < 1) {
+    set_error("%dx%d C=%d K=%d: one image does not fit a launch (tensors must stay below 4 GiB)", H, W, C, K);
     return WINO_E_SHAPE;
   }
-  // stream-K bookkeeping is 32-bit: chunk iterations in all
-  const long long tiles = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
-  if (((tiles + TB - 1) / TB) * (K / KB) * (C / BC) >= (1ll << 31)) {
-    set_error("N=%d %dx%d C=%d K=%d: too many chunk iterations for one launch", N, H, W, C, K);
+  return WINO_OK;
+}
+
+// one launch
+static int check_conv3x3(int N, int H, int W, int C, int K) {
+  if (int rc = check_conv3x3_dims(H, W, C, K)) return rc;
+  if (N < 1 || N > conv3x3_batch_limit(H, W, C, K)) {
+    set_error("bad batch N=%d (one launch takes 1..%lld images of this shape: input/output below 4 GiB)", N,
+              conv3x3_batch_limit(H, W, C, K));
     return WINO_E_SHAPE;
   }
   return WINO_OK;
@@ -261,6 +280,12 @@ static bool use_small_kernel(int N, int H, int W, int C, int K) {
 }
 
 static int conv3x3_prepare(int N, int H, int W, int C, int K, hipStream_t s) {
+  if (int rc = check_conv3x3_dims(H, W, C, K)) return rc;
+  if (N < 1) { set_error("bad batch N=%d", N); return WINO_E_SHAPE; }
+  {   // a batch the launcher splits: its largest launch decides the scratch
+    long long step = conv3x3_batch_limit(H, W, C, K);
+    if (N > step) N = (int)(step > 64 ? step - step % 64 : step);
+  }
   if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
   if (use_small_kernel(N, H, W, C, K)) return WINO_OK;
   int dev = 0;
@@ -287,9 +312,30 @@ static int launch_fused(const FusedParams& prm, int G, int dev, hipStream_t s) {
   return launch_status("wino_f2_fused_kernel");
 }
 
+static int conv3x3_launch_one(const float* in, const float* U, const float* bnBias, const float* bnScale,
+                              float* out, int N, int H, int W, int C, int K, int relu, hipStream_t s);
+
+// Any batch: batches whose tensors would reach 4 GiB go out as several launches of whole images
+// (a multiple of 64 images each, so that every launch but the last fills its 64-tile blocks).
 static int conv3x3_launch(const float* in, const float* U, const float* bnBias, const float* bnScale,
                           float* out, int N, int H, int W, int C, int K, int relu, hipStream_t s) {
   if (!in || !U || !bnBias || !bnScale || !out) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if (int rc = check_conv3x3_dims(H, W, C, K)) return rc;
+  if (N < 1) { set_error("bad batch N=%d", N); return WINO_E_SHAPE; }
+  long long step = conv3x3_batch_limit(H, W, C, K);
+  if (N <= step) return conv3x3_launch_one(in, U, bnBias, bnScale, out, N, H, W, C, K, relu, s);
+  if (step > 64) step -= step % 64;
+  const size_t in_img = (size_t)(H + 2) * (W + 2) * C, out_img = (size_t)(H + 2) * (W + 2) * K;
+  for (long long n0 = 0; n0 < N; n0 += step) {
+    const int n = (int)(N - n0 < step ? N - n0 : step);
+    if (int rc = conv3x3_launch_one(in + (size_t)n0 * in_img, U, bnBias, bnScale, out + (size_t)n0 * out_img,
+                                    n, H, W, C, K, relu, s)) return rc;
+  }
+  return WINO_OK;
+}
+
+static int conv3x3_launch_one(const float* in, const float* U, const float* bnBias, const float* bnScale,
+                              float* out, int N, int H, int W, int C, int K, int relu, hipStream_t s) {
   if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
   const bool fixed14 = H == WINO_PQ && W == WINO_PQ;
   if (use_small_kernel(N, H, W, C, K)) {

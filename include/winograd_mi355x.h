@@ -108,6 +108,9 @@ int wino_filter_import_f4(const float* u36, float* U, int C, int K, wino_stream_
 int wino_conv3x3_bn_relu(const float* in, const float* U, const float* bnBias,
                          const float* bnScale, float* out, int N, int C, int K, int relu,
                          wino_stream_t s);
+/* Any N >= 1: one launch addresses its tensors with 32-bit byte offsets, so a batch whose input or
+ * output would reach 4 GiB (N >= 16384 at 256 channels) goes out as several launches of whole images
+ * on `s`.  wino_conv3x3_plan describes one launch and rejects such a batch. */
 /* Allocates that scratch for (current device, `s`) and this shape ahead of time -- e.g. before
  * capturing wino_conv3x3_bn_relu / wino_residual_block into a HIP graph, where an allocation inside
  * the capture is not allowed.  Optional otherwise. */

@@ -624,6 +624,41 @@ def test_residual_block(N, C4, Cm, pkg, O, torch_dev):
     assert (want > 0).mean() > 0.2  # the test exercises both sides of the final ReLU
 
 
+def test_conv3x3_batch_beyond_one_launch(pkg, O, torch_dev):
+    """One launch addresses its tensors with 32-bit byte offsets (< 4 GiB each); the entry point takes
+    any batch and cuts larger ones into launches of whole images.  5100 images of 56x56x64 are 4.4 GB
+    in and 4.4 GB out: 4928 + 172.  The first and last image and the two on either side of the cut
+    against the fp64 oracle, zero ring, every output finite."""
+    torch, dev = torch_dev
+    N, H, W, C, K = 5100, 56, 56, 64, 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12 * (1 << 30):
+        pytest.skip("needs 12 GiB of free device memory")
+    per_image = (H + 2) * (W + 2) * max(C, K) * 4
+    limit = ((1 << 32) - 1) // per_image
+    cut = limit - limit % 64
+    assert cut < N <= 2 * cut
+    g = torch.Generator(device=dev).manual_seed(6)
+    x = torch.rand(N, H + 2, W + 2, C, device=dev, generator=g) - 0.5
+    rng = np.random.RandomState(6)
+    w = (rng.rand(K, C, 3, 3) - 0.5).astype(np.float32)
+    s = (rng.rand(K) - 0.5).astype(np.float32)
+    b = (rng.rand(K) - 0.5).astype(np.float32)
+    U = pkg.filter_transform_f2(_t(torch_dev, w))
+    out = torch.full((N, H + 2, W + 2, K), float("nan"), device=dev)
+    pkg.conv3x3_bn_relu(x, U, _t(torch_dev, b), _t(torch_dev, s), relu=True, out=out)
+    assert bool(torch.isfinite(out).all())
+    ring = np.ones((H + 2, W + 2), bool)
+    ring[1:-1, 1:-1] = False
+    for n in (0, cut - 1, cut, N - 1):
+        got = out[n:n + 1].cpu().numpy()
+        want = O.conv3x3_bn_relu_direct(x[n:n + 1].cpu().numpy(), w, s, b, relu=True)
+        assert O.rel_error(got, want) < TIGHT, n
+        assert (got[:, ring, :] == 0).all(), n
+    del x, out
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------ random legal shapes
 def test_random_legal_shapes(pkg, O, torch_dev):
     """Seeded sweep over shapes the C-ABI declares legal (1x1: any M, Cin % 32, Kout % 64; 3x3: any
