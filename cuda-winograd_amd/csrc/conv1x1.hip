@@ -69,16 +69,17 @@ static inline bool four_waves(int Cin, int Kout) { return Kout <= 128 || Cin <= 
 // one-tile-per-workgroup launch.  A launch lasts as long as its busiest CU (conv1x1_kernel.h): the
 // plain form puts r = ceil(tiles / cus) whole tiles on it, stream-K x = tiles * nk / cus k-steps
 // plus a hand-over per range, at the end of the range, on the critical path.  Launch times in us
-// fitted to ~60 measurements on MI355X (the four reference layers, N = 1..192, G = cus and 2 cus;
-// reproduced to 1-3 %):
-//                        8 waves (128 columns)              4 waves (64 columns)
-//   plain                3 + r (1.80 nk + 0.9)              5.3 + r (0.82 nk + 0.7)
-//   stream-K, G = cus    11 + x (1.79 + 0.9 / nk)           9 + x (0.96 + 0.7 / nk)
-//   stream-K, G = 2 cus  15 + x (1.67 + 0.9 / nk)           12 + x (0.80 + 0.7 / nk)
-// (the 0.9 / 0.7 is a whole tile's epilogue; two ranges per CU run the steps a little faster and pay
-// a second hand-over).  The cheapest predicted form wins; stream-K must come in under 0.96 of plain.
-// What that buys at the reference shapes: 1024->256 N = 128 118 -> 109 us, N = 80..112 116 -> 73..98,
-// N = 160 171 -> 133; 512->128 N = 80 32 -> 27, N = 160 47 -> 42, N = 128 stays plain (32 vs 35).
+// fitted to measurements on MI355X (the four reference layers and 2048->512, 768->192, N = 1..256,
+// K loops of 8..64 steps, 1..4 rounds, G = cus and 2 cus; reproduced to 1-3 %; refitted after the
+// loop of this kernel lost a quarter of its instructions):
+//                        8 waves (128 columns)               4 waves (64 columns)
+//   plain                2.7 + r (1.555 nk + 1.75)           3.8 + r (0.778 nk + 0.7)
+//   stream-K, G = cus    12 + x (1.60 + 1.75 / nk)           9.5 + x (0.89 + 0.7 / nk)
+//   stream-K, G = 2 cus  13 + x (1.558 + 1.75 / nk)          11 + x (0.816 + 0.7 / nk)
+// (the 1.75 / 0.7 is a whole tile's epilogue; two ranges per CU run the steps a little faster and pay
+// a second hand-over).  The cheapest predicted form wins; stream-K must come in under 0.99 of plain.
+// What that buys at the reference shapes: 1024->256 N = 128 106 -> 102 us, N = 80..120 105 -> 71..99,
+// N = 160 156 -> 127; 512->128 N = 80 30 -> 26, N = 160 43 -> 40, N = 128 stays plain.
 //
 // Tiny problems -- fewer k-steps than 4 per CU, the reference's own N = 1 protocol -- leave CUs idle
 // in any form; split-K over G = steps / 4 ranges (a tile's 4-16 segments gathered in k order by
@@ -94,8 +95,8 @@ static inline bool four_waves(int Cin, int Kout) { return Kout <= 128 || Cin <= 
 constexpr int SK1_SMALL_STEPS = 4, SK1_SMALL_MIN_NK = 16, SK1_MIN_STEPS = 4;
 constexpr long long SK1_MAX_GRID = 16384;   // 2 * G slabs of <= 56 KB must stay below the 4 GiB a buffer descriptor spans
 struct Sk1Model { double a_plain, t_plain, e_tile, a_sk1, t_sk1, a_sk2, t_sk2; };
-constexpr Sk1Model SK1_MODEL_8W = {3.0, 1.80, 0.9, 11.0, 1.79, 15.0, 1.67};
-constexpr Sk1Model SK1_MODEL_4W = {5.3, 0.82, 0.7, 9.0, 0.96, 12.0, 0.80};
+constexpr Sk1Model SK1_MODEL_8W = {2.7, 1.555, 1.75, 12.0, 1.60, 13.0, 1.558};
+constexpr Sk1Model SK1_MODEL_4W = {3.8, 0.778, 0.7, 9.5, 0.89, 11.0, 0.816};
 static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_form) {
   const char* f_env = getenv("WINO_1X1_SK");
   const char* g_env = getenv("WINO_1X1_SK_GRID");
@@ -134,7 +135,7 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_f
   const double t_sk2 = G2 ? m.a_sk2 + x * (m.t_sk2 + m.e_tile / nk) : 1e30;
   const long long G = t_sk2 < t_sk1 ? G2 : G1;
   if (force == 1) return (int)G;
-  return (t_sk2 < t_sk1 ? t_sk2 : t_sk1) < 0.96 * t_plain ? (int)G : 0;
+  return (t_sk2 < t_sk1 ? t_sk2 : t_sk1) < 0.99 * t_plain ? (int)G : 0;
 }
 
 template <int BK, int NW>
