@@ -83,7 +83,7 @@ static inline bool four_waves(int Cin, int Kout) { return Kout <= 128 || Cin <= 
 //
 // Tiny problems -- fewer k-steps than 4 per CU, the reference's own N = 1 protocol -- leave CUs idle
 // in any form; split-K over G = steps / 4 ranges (a tile's 4-16 segments gathered in k order by
-// whoever arrives last): 1024->256 59 -> 19-25 us for N <= 16, 512->128 18 -> 11-13 us.  Taken when
+// whoever arrives last): 1024->256 54 -> 19-25 us for N <= 16, 512->128 16-17 -> 11.5-13 us.  Taken when
 // the K loop has at least 16 steps and a range plus its hand-over (about 5 steps) stays below 0.8 of
 // a plain workgroup's nk + 1.6 (epilogue) steps: 256->1024 (8 steps) would gain < 25 % at N <= 2 and
 // lose from N = 16, 128->512 (4 steps) always loses.
