@@ -659,6 +659,53 @@ def test_conv3x3_batch_beyond_one_launch(pkg, O, torch_dev):
     torch.cuda.empty_cache()
 
 
+def test_streamk_scratch_is_never_stale(pkg, O, torch_dev, monkeypatch):
+    """The hand-over slabs are the same memory in every launch, written by one workgroup and read
+    by another, possibly on another XCD.  Launches that repeat the same inputs cannot tell a fresh
+    slab from a line cached by an earlier launch; two different inputs alternated can: each result
+    must equal the one its own input gives in the plain (1x1) or whole-item (3x3) form, to summation
+    order, and must be bitwise what the same input gave the time before."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(314)
+    t = lambda a: _t(torch_dev, a)
+    # 1x1: many partial tiles per launch
+    M, Cin, Kout = 9 * 196, 512, 256
+    Bm = t((rng.rand(Cin, Kout) - 0.5).astype(np.float32))
+    sc, bi = t((rng.rand(Kout) - 0.5).astype(np.float32)), t((rng.rand(Kout) - 0.5).astype(np.float32))
+    As = [t(((rng.rand(M, Cin) - 0.5) * s).astype(np.float32)) for s in (1.0, 37.0)]
+    monkeypatch.setenv("WINO_1X1_SK", "0")
+    monkeypatch.delenv("WINO_1X1_SK_GRID", raising=False)
+    plain = [pkg.conv1x1_bn(a, Bm, bi, sc, False).clone() for a in As]
+    monkeypatch.setenv("WINO_1X1_SK", "1")
+    monkeypatch.setenv("WINO_1X1_SK_GRID", "120")
+    first = [None, None]
+    for rep in range(12):
+        i = rep & 1
+        got = pkg.conv1x1_bn(As[i], Bm, bi, sc, False)
+        assert float((got - plain[i]).abs().max()) < 4e-6 * float(plain[i].abs().max()), (rep, i)
+        if first[i] is None:
+            first[i] = got.clone()
+        assert torch.equal(got, first[i]), (rep, i)
+    # 3x3: every item cut into segments
+    N, C, K = 9, 64, 128
+    monkeypatch.setenv("WINO_3X3_ALGO", "big")
+    w = (rng.rand(K, C, 3, 3) - 0.5).astype(np.float32)
+    U = pkg.filter_transform_f2(t(w))
+    s3, b3 = t((rng.rand(K) - 0.5).astype(np.float32)), t((rng.rand(K) - 0.5).astype(np.float32))
+    xs = [t(((rng.rand(N, 16, 16, C) - 0.5) * s).astype(np.float32)) for s in (1.0, 53.0)]
+    monkeypatch.setenv("WINO_SK_GRID", "8")      # items / 8 whole-item rounds, short tail
+    whole = [pkg.conv3x3_bn_relu(x, U, b3, s3, relu=False).clone() for x in xs]
+    monkeypatch.setenv("WINO_SK_GRID", "200")    # more workgroups than items: everything is tail
+    first = [None, None]
+    for rep in range(12):
+        i = rep & 1
+        got = pkg.conv3x3_bn_relu(xs[i], U, b3, s3, relu=False)
+        assert float((got - whole[i]).abs().max()) < 4e-6 * float(whole[i].abs().max()), (rep, i)
+        if first[i] is None:
+            first[i] = got.clone()
+        assert torch.equal(got, first[i]), (rep, i)
+
+
 # ------------------------------------------------------------------ random legal shapes
 def test_random_legal_shapes(pkg, O, torch_dev):
     """Seeded sweep over shapes the C-ABI declares legal (1x1: any M, Cin % 32, Kout % 64; 3x3: any
