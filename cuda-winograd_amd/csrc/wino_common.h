@@ -24,6 +24,7 @@ int hip_fail(hipError_t e, const char* what);
 // one stream run one after the other, so the 3x3 and the 1x1 kernels share a stream's set.
 // Counters are zero at allocation and returned to zero by every launch's last arrivers.
 int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, float** slabs, unsigned** tickets);
+int sk_scratch_release(hipStream_t s);   // wino_stream_destroy: the stream's scratch, on every device
 int device_cus(int dev, int* cus);
 
 #define WINO_HIP(call)                                          \

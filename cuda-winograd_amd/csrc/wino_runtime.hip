@@ -66,6 +66,22 @@ int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, floa
   return WINO_OK;
 }
 
+// Frees the scratch of `s` on every device (the stream is going away; its handle may be reused).
+int sk_scratch_release(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  int cur = 0;
+  WINO_HIP(hipGetDevice(&cur));
+  for (size_t i = 0; i < g_ws.size();) {
+    if (g_ws[i].stream != s) { i++; continue; }
+    WINO_HIP(hipSetDevice(g_ws[i].dev));
+    if (g_ws[i].slabs) WINO_HIP(hipFree(g_ws[i].slabs));
+    if (g_ws[i].tickets) WINO_HIP(hipFree(g_ws[i].tickets));
+    g_ws.erase(g_ws.begin() + (long)i);
+  }
+  WINO_HIP(hipSetDevice(cur));
+  return WINO_OK;
+}
+
 int device_cus(int dev, int* cus) {
   static std::atomic<int> cache[64];
   int c = dev >= 0 && dev < 64 ? cache[dev].load() : 0;
@@ -154,6 +170,9 @@ int wino_stream_create(wino_stream_t* stream) {
 
 int wino_stream_destroy(wino_stream_t stream) {
   if (!stream) return WINO_OK;
+  // the stream's work is done before its stream-K scratch goes away
+  WINO_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (int rc = sk_scratch_release((hipStream_t)stream)) return rc;
   WINO_HIP(hipStreamDestroy((hipStream_t)stream));
   return WINO_OK;
 }

@@ -69,7 +69,7 @@ int wino_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int wino_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes);
 int wino_device_synchronize(void);
 int wino_stream_create(wino_stream_t* stream);
-int wino_stream_destroy(wino_stream_t stream);
+int wino_stream_destroy(wino_stream_t stream);   /* waits for the stream, frees the library's scratch of it */
 int wino_stream_synchronize(wino_stream_t stream);
 /* events: timing on the stream the kernels run on (hipEvent based) */
 int wino_event_create(void** event);

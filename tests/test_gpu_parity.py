@@ -706,6 +706,42 @@ def test_streamk_scratch_is_never_stale(pkg, O, torch_dev, monkeypatch):
         assert torch.equal(got, first[i]), (rep, i)
 
 
+def test_streams_created_and_destroyed_do_not_leak_scratch(pkg, O, torch_dev, monkeypatch):
+    """The stream-K scratch is owned by the library per (device, stream); wino_stream_destroy gives
+    it back.  Fifty short-lived C-ABI streams, a stream-K launch on each: results right, device
+    memory where it was (one stream's scratch is 32 MiB; a leak would cost 1.6 GB)."""
+    torch, dev = torch_dev
+    L = pkg.lib()
+    rng = np.random.RandomState(50)
+    M, Cin, Kout = 5 * 196, 512, 128
+    A = ((rng.rand(M, Cin) - 0.5) * 4).astype(np.float32)
+    B = ((rng.rand(Cin, Kout) - 0.5) * 4).astype(np.float32)
+    s = (rng.rand(Kout) - 0.5).astype(np.float32)
+    b = (rng.rand(Kout) - 0.5).astype(np.float32)
+    At, Bt, bt, st = (_t(torch_dev, a) for a in (A, B, b, s))
+    out = torch.empty(M, Kout, device=dev)
+    want = O.conv1x1_bn(A, B, b, s, True)
+    monkeypatch.setenv("WINO_1X1_SK", "1")
+    monkeypatch.setenv("WINO_1X1_SK_GRID", "64")
+    torch.cuda.synchronize()
+    free0 = None
+    for i in range(50):
+        h = ctypes.c_void_p()
+        assert L.wino_stream_create(ctypes.byref(h)) == 0
+        out.zero_()
+        torch.cuda.synchronize()
+        rc = L.wino_conv1x1_bn(At.data_ptr(), Bt.data_ptr(), bt.data_ptr(), st.data_ptr(), out.data_ptr(),
+                               M, Cin, Kout, 1, h)
+        assert rc == 0, L.wino_last_error_string()
+        assert L.wino_stream_destroy(h) == 0      # waits for the launch
+        if i in (0, 49):
+            assert O.rel_error(out.cpu().numpy(), want) < TIGHT
+        if i == 4:
+            free0 = torch.cuda.mem_get_info()[0]
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 * (1 << 20), (free0, free1)
+
+
 # ------------------------------------------------------------------ random legal shapes
 def test_random_legal_shapes(pkg, O, torch_dev):
     """Seeded sweep over shapes the C-ABI declares legal (1x1: any M, Cin % 32, Kout % 64; 3x3: any
