@@ -40,7 +40,7 @@ oracle/liboracle.so: oracle/cpu_conv.c
 	$(CC) -O3 -march=x86-64-v3 -fPIC -shared -std=gnu11 -o $@ $< -lpthread -lm
 
 # developer tools (ablation of the fused kernel, fp32 MFMA ceiling); not part of the library
-tools: tools/ablate_fused tools/ablate_1x1 tools/mfma_peak tools/coissue tools/mixbench
+tools: tools/ablate_fused tools/ablate_1x1 tools/mfma_peak tools/coissue tools/mixbench tools/occ1x1
 tools/ablate_1x1: tools/ablate_1x1.hip $(wildcard $(CSRC)/*.h)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) $< -o $@
 tools/ablate_fused: tools/ablate_fused.hip $(wildcard $(CSRC)/*.h)
@@ -54,8 +54,10 @@ tools/mfma_peak: tools/mfma_peak.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 tools/mixbench: tools/mixbench.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
+tools/occ1x1: tools/occ1x1.hip $(wildcard $(CSRC)/*.h)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) $< -o $@
 
 clean:
-	rm -rf $(BUILD) $(LIB) Test oracle/liboracle.so tools/ablate_fused tools/ablate_1x1 tools/mfma_peak tools/coissue tools/mixbench
+	rm -rf $(BUILD) $(LIB) Test oracle/liboracle.so tools/ablate_fused tools/ablate_1x1 tools/mfma_peak tools/coissue tools/mixbench tools/occ1x1
 
 .PHONY: all oracle tools clean

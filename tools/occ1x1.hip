@@ -1,0 +1,51 @@
+// Developer tool: how much does the number of co-resident workgroups per CU matter to the 4-wave
+// form of the 1x1 kernel on the short-K reference layers?  Same kernel, same grid; the dynamic LDS
+// request is padded so that 3, 2 or 1 workgroups fit a CU.
+#include "conv1x1_kernel.h"
+#include <cstdlib>
+#include <vector>
+namespace wino { void set_error(const char*, ...) {} int hip_fail(hipError_t, const char*) { return -1; } }
+using namespace wino::gemm1x1;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+template <int NW>
+float run(const float* A, const float* B, const float* b, const float* s, float* C, long M, int Cin, int Kout, int lds) {
+  using G = Cfg<32, NW>;
+  CK(hipFuncSetAttribute((const void*)(conv1x1_bn_kernel<32, NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+  const int nMB = (int)((M + BM - 1) / BM);
+  const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto launch = [&] { hipLaunchKernelGGL((conv1x1_bn_kernel<32, NW, 0>), dim3(grid), dim3(G::NT), lds, 0, A, B, b, s, (const float*)nullptr, C, M, Cin, Kout, 1, nMB, 0L, 0L, 0L, SkArgs{nullptr, nullptr}, make_padgeo(14, 14)); };
+  for (int i = 0; i < 10; i++) launch();
+  CK(hipDeviceSynchronize());
+  float best = 1e9f;
+  for (int t = 0; t < 3; t++) {
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 50; i++) launch();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms * 20.f < best ? ms * 20.f : best;
+  }
+  return best;
+}
+int main() {
+  const long M = 128 * 196;
+  float *A, *B, *b, *s, *C;
+  CK(hipMalloc(&A, M * 1024 * 4)); CK(hipMalloc(&B, 1024 * 1024 * 4)); CK(hipMalloc(&C, M * 1024 * 4));
+  CK(hipMalloc(&b, 4096)); CK(hipMalloc(&s, 4096));
+  std::vector<float> h(M * 1024);
+  for (auto& x : h) x = (float)(rand() & 0xffff) / 65536.f - 0.5f;
+  CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(B, h.data(), 1024 * 1024 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b, h.data(), 4096, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + 1024, 4096, hipMemcpyHostToDevice));
+  printf("us per launch, N=128, plain form        | 3 per CU  2 per CU  1 per CU   (4-wave form, LDS request 44 / 60 / 100 KB)\n");
+  const int shapes[4][2] = {{128, 512}, {512, 128}, {256, 1024}, {1024, 256}};
+  for (auto& sh : shapes)
+    printf("%5d->%-5d 4 waves                     | %8.1f %9.1f %9.1f\n", sh[0], sh[1],
+           run<4>(A, B, b, s, C, M, sh[0], sh[1], Cfg<32, 4>::LDS_BYTES), run<4>(A, B, b, s, C, M, sh[0], sh[1], 61440),
+           run<4>(A, B, b, s, C, M, sh[0], sh[1], 102400));
+  printf("                                        | 2 per CU  1 per CU             (8-wave form, LDS request 60 / 100 KB)\n");
+  for (auto& sh : shapes)
+    printf("%5d->%-5d 8 waves                     | %8.1f %9.1f\n", sh[0], sh[1],
+           run<8>(A, B, b, s, C, M, sh[0], sh[1], Cfg<32, 8>::LDS_BYTES), run<8>(A, B, b, s, C, M, sh[0], sh[1], 102400));
+  return 0;
+}
