@@ -6,12 +6,13 @@
 // with A [M][Cin] (pixels x in-channels, the reference's HWC-flat activations),
 // B [Cin][Kout] row-major exactly as the reference stores it (Kernel128_one.cu:40-42).
 //
-// Tiling: workgroup = NW waves (8, or 4 when Kout <= 128) computes BM=112 x BN=16*NW of C; the
+// Tiling: workgroup = NW waves (8, or 4: see four_waves() below) computes BM=112 x BN=16*NW of C; the
 // K-loop runs over Cin in steps of BK = 32 through two LDS stages (60 / 44 KB, so 2-3 workgroups
-// share a CU) filled by LDS-DMA.  BM = 7 MFMA row blocks because the reference's M = N*196 = 2^a * 49:
-// 112-row tiles cover it exactly (25088 = 224 * 112) and 224 tiles fill one round of the 256
-// CUs at Kout = 128.  Wave w owns columns [16w, 16w+16): 7 accumulator tiles of
-// v_mfma_f32_16x16x4_f32 (28 acc VGPRs); the A fragment of a step is shared by 4 MFMAs.
+// share a CU) filled by LDS-DMA through buffer descriptors (conv1x1_kernel.h).  BM = 7 MFMA row
+// blocks because the reference's M = N*196 = 2^a * 49: 112-row tiles cover it exactly (25088 =
+// 224 * 112).  Wave w owns columns [16w, 16w+16): 7 accumulator tiles of v_mfma_f32_16x16x4_f32
+// (28 acc VGPRs); the A fragment of a step is shared by 4 MFMAs.  Shapes whose tile count does not
+// fill the CUs evenly are launched in stream-K / split-K form (sk1_grid below).
 //
 // LDS images (16-byte units XOR-permuted on the DMA source side so that fragment reads are
 // bank-conflict free):

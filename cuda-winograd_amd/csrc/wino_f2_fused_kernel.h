@@ -15,7 +15,7 @@
 //   * whole-item rounds: ndp = items / G rounds in which workgroup l owns item r*G + l outright.
 //     All workgroups then walk the same chunk index at the same time, so the K/64 k-blocks that
 //     share a tile block's patches and the tile blocks that share a filter chunk hit each other's
-//     lines in the XCD's L2 (88 % hit rate);
+//     lines in the XCD's L2 (about 80 % hit rate over the whole launch, profiles/);
 //   * a stream-K tail for the remaining items % G items: their chunk iterations, in item-major
 //     order, are cut into G equal contiguous ranges.  At 256 channels and N = 128: 392 items on
 //     256 CUs = one whole item (32 iterations) + 17 tail iterations each = 49 per CU, instead of
