@@ -26,7 +26,6 @@ int hip_fail(hipError_t e, const char* what);
 int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, float** slabs, unsigned** tickets);
 int sk_scratch_release(hipStream_t s);   // wino_stream_destroy: the stream's scratch, on every device
 int device_cus(int dev, int* cus);
-
 #define WINO_HIP(call)                                          \
   do {                                                          \
     hipError_t e_ = (call);                                     \
@@ -71,6 +70,10 @@ __device__ __forceinline__ void slab_store16(f32x4 v, buffer_rsrc_t rsrc, unsign
 __device__ __forceinline__ void buf_store16(f32x4 v, buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_vs, v), rsrc, voff, soff, 0);
 }
+// the same, non-temporal (nt): write-once data that should not displace what others re-read from L2
+__device__ __forceinline__ void buf_store16_nt(f32x4 v, buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_vs, v), rsrc, voff, soff, 2);
+}
 __device__ __forceinline__ f32x4 slab_load16(buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16));
 }
@@ -80,6 +83,7 @@ __device__ inline buffer_rsrc_t make_rsrc(const void*, unsigned) { return 0; }
 __device__ inline void dma16_buf(buffer_rsrc_t, unsigned, unsigned, void*) {}
 __device__ inline void slab_store16(f32x4, buffer_rsrc_t, unsigned, unsigned) {}
 __device__ inline void buf_store16(f32x4, buffer_rsrc_t, unsigned, unsigned) {}
+__device__ inline void buf_store16_nt(f32x4, buffer_rsrc_t, unsigned, unsigned) {}
 __device__ inline f32x4 slab_load16(buffer_rsrc_t, unsigned, unsigned) { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 #endif
 

@@ -756,7 +756,13 @@ wino_f2_fused_kernel(const FusedParams prm) {
         //  range check returns 0 there; a Winograd output only depends on its own 3x3 window, so
         //  the kept outputs are unaffected, and the surplus ones must not reach the ring)
         const bool keep = live && (!GEN || (py <= Hp - 2 && pxx <= Wp - 2));
-        if (keep) buf_store16(val, rsrc_out, (unsigned)((img + py * Wp + pxx) * K * sizeof(float)) + kbyte, 0);
+        // Non-temporal: the output is written once and, at 33 MB for the reference layer, exceeds the
+        // 32 MB of L2 anyway.  Old and new libraries interleaved: 256ch 125.4 -> 123.9 us, 128ch
+        // 43.5 -> 41.95, the other feature maps -0.4..-1.8 %; HBM bytes and L2 hit rate unchanged;
+        // the bottleneck blocks, whose last launch reads this output at once, within +-0.3 %.
+        // (A run-time choice between the two store forms cost more than it saved: its extra live
+        // scalar pushed SGPR spill code into the MFMA loop.)
+        if (keep) buf_store16_nt(val, rsrc_out, (unsigned)((img + py * Wp + pxx) * K * sizeof(float)) + kbyte, 0);
       }
     }
     phase(3);
