@@ -134,6 +134,14 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   constexpr int BN = G::BN;
   const bool relu = flags & WINO_RELU, a_padded = flags & WINO_A_PADDED;
   const bool c_padded = flags & WINO_C_PADDED, add_res = flags & WINO_ADD_RESIDUAL;
+  // Output stores: non-temporal when the output is written once and the layer is MFMA-bound (a K
+  // loop of at least 4 steps) -- the L2 then stays with the A / B lines other workgroups re-read.
+  // Old and new libraries interleaved: 512->128 31.95 -> 31.1 us, 128->512 36.25 -> 35.6, 1024->256
+  // 100.95 -> 100.4, 256->1024 102.9 -> 102.6, the 14x14 and 28x28 bottleneck blocks -0.6 %.
+  // Cached when the output is the padded input of a 3x3 layer (read again at once) and for short
+  // K loops, which are bound by the stores themselves and lose the L2's write combining (with
+  // streaming stores everywhere the 56x56 block, whose last layer is 64->256, went 522 -> 533 us).
+  const bool stream_out = !c_padded && Cin >= 4 * BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NBLK = Kout / BN;
   const int bid = blockIdx.x;
@@ -424,26 +432,34 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     constexpr int RPW = BM / NW;         // rows per wave
     static_assert(RPW % RPI == 0, "rows per wave must be a whole number of store instructions");
     const int c4 = (lane % LPR) * 4;
+    // Two copies of the row loop under one uniform branch, one per store form: inside a shared
+    // loop the optimizer folds the two stores into one plain store, and an opaque pointer that
+    // prevents that costs the cached form 1-2 % on the short-K layers.
+    auto store_rows = [&](auto stream_c) {
 #pragma unroll
-    for (int k = 0; k < RPW / RPI; k++) {
-      const int row = w * RPW + k * RPI + lane / LPR;
-      f32x4 val = *(const f32x4*)(img + row * BN + (c4 ^ (((row >> 2) & 3) << 4)));
-      const long grow = m0 + row;
-      if (grow < M) {
-        if (add_res) {
-          const f32x4 r = *(const f32x4*)(R + grow * Kout + n0 + c4);
-          val += r;
-          if (relu) {
+      for (int k = 0; k < RPW / RPI; k++) {
+        const int row = w * RPW + k * RPI + lane / LPR;
+        f32x4 val = *(const f32x4*)(img + row * BN + (c4 ^ (((row >> 2) & 3) << 4)));
+        const long grow = m0 + row;
+        if (grow < M) {
+          if (add_res) {
+            const f32x4 r = *(const f32x4*)(R + grow * Kout + n0 + c4);
+            val += r;
+            if (relu) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
+              for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
+            }
           }
+          // c_padded: row = pixel (n, y, x) of the H x W map -> interior of [N][H+2][W+2][Kout]
+          // (its zero ring is written by the ring pass at the top of the kernel)
+          const long orow = c_padded ? padded_row(grow, pg) : grow;
+          if (decltype(stream_c)::value) __builtin_nontemporal_store(val, (f32x4*)(Cout + orow * Kout + n0 + c4));
+          else *(f32x4*)(Cout + orow * Kout + n0 + c4) = val;
         }
-        // c_padded: row = pixel (n, y, x) of the H x W map -> interior of [N][H+2][W+2][Kout]
-        // (its zero ring is written by the ring pass at the top of the kernel)
-        const long orow = c_padded ? padded_row(grow, pg) : grow;
-        *(f32x4*)(Cout + orow * Kout + n0 + c4) = val;
       }
-    }
+    };
+    if (stream_out) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
   }
   }   // segments
 }
