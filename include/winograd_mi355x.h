@@ -39,6 +39,12 @@
 extern "C" {
 #endif
 
+/* Bumped when an existing entry point changes meaning or signature; additions leave it alone.
+ * Added since the first cut of version 1 (all additive): wino_conv3x3_prepare(_hw),
+ * wino_conv3x3_bn_relu_hw, wino_conv3x3_direct_hw, wino_conv3x3_plan, wino_conv3x3_f4_*,
+ * wino_conv1x1_prepare, wino_conv1x1_plan, wino_conv1x1_bn_ex_hw, wino_residual_block_hw,
+ * wino_residual_block_workspace_bytes_hw; wino_stream_destroy now also releases the stream's
+ * scratch; wino_conv3x3_bn_relu(_hw) take any batch (they used to reject tensors of 4 GiB). */
 #define WINO_ABI_VERSION 1
 
 enum {
