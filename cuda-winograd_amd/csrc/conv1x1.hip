@@ -82,18 +82,16 @@ static inline bool four_waves(int Cin, int Kout) { return Kout <= 128 || Cin <= 
 // What that buys at the reference shapes: 1024->256 N = 128 106 -> 102 us, N = 80..120 105 -> 71..99,
 // N = 160 156 -> 127; 512->128 N = 80 30 -> 26, N = 160 43 -> 40, N = 128 stays plain.
 //
-// Tiny problems -- fewer k-steps than 4 per CU, the reference's own N = 1 protocol -- leave CUs idle
-// in any form; split-K over G = steps / 4 ranges (a tile's 4-16 segments gathered in k order by
-// whoever arrives last): 1024->256 54 -> 19-25 us for N <= 16, 512->128 16-17 -> 11.5-13 us.  Taken when
-// the K loop has at least 16 steps and a range plus its hand-over (about 5 steps) stays below 0.8 of
-// a plain workgroup's nk + 1.6 (epilogue) steps: 256->1024 (8 steps) would gain < 25 % at N <= 2 and
-// lose from N = 16, 128->512 (4 steps) always loses.
+// Tiny problems -- too few k-steps to give every CU a range, the reference's own N = 1 protocol --
+// leave CUs idle in any form; split-K over short ranges (a tile's segments gathered in k order by
+// whoever arrives last): 1024->256 54 -> 19-25 us for N <= 16, 512->128 16-17 -> 11.5-13 us,
+// 256->1024 17 -> 13.5 us at N = 1; 128->512 (4 steps) always loses.  See the model in sk1_grid.
 //
 // Developer overrides, read per call so that tests can sweep the decomposition: WINO_1X1_SK=0 / 1
 // forces the plain / stream-K form (1: whenever a legal grid exists), WINO_1X1_SK_GRID=G sets the
 // number of ranges (rounded down to a multiple of 8 and of the column blocks, at most one range
 // per k-step).
-constexpr int SK1_SMALL_STEPS = 4, SK1_SMALL_MIN_NK = 16, SK1_MIN_STEPS = 4;
+constexpr int SK1_MIN_STEPS = 4;
 constexpr long long SK1_MAX_GRID = 16384;   // 2 * G slabs of <= 56 KB must stay below the 4 GiB a buffer descriptor spans
 struct Sk1Model { double a_plain, t_plain, e_tile, a_sk1, t_sk1, a_sk2, t_sk2; };
 constexpr Sk1Model SK1_MODEL_8W = {2.7, 1.555, 1.75, 12.0, 1.60, 13.0, 1.558};
@@ -115,15 +113,31 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_f
     G -= G % step;
     return G >= step ? (int)G : 0;
   }
-  if (U / SK1_SMALL_STEPS < cus) {   // tiny: split-K, fewer ranges than CUs
-    long long G = U / SK1_SMALL_STEPS;
-    G -= G % step;
-    if (G < step || G <= tiles) return 0;
-    if (force == 1) return (int)G;
-    const double sk_steps = (double)U / (double)G + 5.0, plain_steps = nk + 1.6;
-    return nk >= SK1_SMALL_MIN_NK && sk_steps < 0.8 * plain_steps ? (int)G : 0;
-  }
   const Sk1Model& m = four_wave_form ? SK1_MODEL_4W : SK1_MODEL_8W;
+  {
+    // Tiny problems: split-K over ranges of s k-steps.  A tile's nk / s segments are gathered one
+    // after the other by whoever arrives last, so  T = a + s t + (nk / s) c  with, per segment,
+    // c = 0.9 us (8 waves, 56 KB slabs) or 0.47 us (4 waves, 28 KB) and a = 6.7 / 7.2 us, fitted at
+    // N = 1..4 (1024->256: s = 8 / 4 / 2 gives 23.1 / 19.1 / 21.9 us; 256->1024: s = 4 / 2 / 1 gives
+    // 14.7 / 13.4 / 16.8; 2048->64: s = 16 / 4 gives 21.5 / 17.8).  Its optimum s* = sqrt(c nk / t) is
+    // 4 steps for the 32-step layers, 2 for 256->1024's 8, 3-6 for the 4-wave layers.
+    const double c_seg = four_wave_form ? 0.47 : 0.9, a_tiny = four_wave_form ? 7.2 : 6.7;
+    int s_opt = (int)(__builtin_sqrt(c_seg * nk / m.t_plain) + 0.5);
+    // (the model is flat near its optimum and has no term for the total slab traffic, which grows
+    //  with the tile count: 512->128 at N = 4 measured 11.7 us with 4-step ranges, 12.6 with 3)
+    if (s_opt < (nk >= 16 ? 4 : 2)) s_opt = nk >= 16 ? 4 : 2;
+    if (s_opt > nk) s_opt = nk;
+    if (U / s_opt < cus) {   // fewer such ranges than CUs: the general forms below do not apply
+      long long G = U / s_opt;
+      G -= G % step;
+      if (G < step || G <= tiles) return 0;
+      if (force == 1) return (int)G;
+      const double s_eff = (double)U / (double)G;
+      const double t_sk = a_tiny + s_eff * m.t_plain + ((double)nk / s_eff) * c_seg;
+      const double t_plain = m.a_plain + m.t_plain * nk + m.e_tile;
+      return t_sk < 0.9 * t_plain ? (int)G : 0;
+    }
+  }
   const long long rounds = (tiles + cus - 1) / cus;
   const double x = (double)U / (double)cus;
   const double t_plain = m.a_plain + (double)rounds * (m.t_plain * nk + m.e_tile);

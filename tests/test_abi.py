@@ -236,7 +236,8 @@ def test_one_by_one_plan_covers_every_step_once(M, Cin, Kout, cus, grid_env, pkg
     if (M, Cin, Kout, cus, grid_env) in ((25088, 512, 128, 256, None), (25088, 256, 1024, 256, None), (25088, 128, 512, 256, None)):
         assert sk == 0                        # 14 steps per range: not worth the hand-over; exact rounds
     # small batches (fewer tiles than CUs): split-K when the K loop is long enough to pay for the hand-over
-    small = {(196, 1024, 256): (1, 32), (196, 512, 128): (1, 16), (196, 256, 1024): (0, None), (196, 128, 512): (0, None),
+    # (4-step ranges for the 32- and 16-step layers, 2-step ranges for 256->1024's 8, never for 128->512's 4)
+    small = {(196, 1024, 256): (1, 32), (196, 512, 128): (1, 16), (196, 256, 1024): (1, 64), (196, 128, 512): (0, None),
              (32 * 196, 1024, 256): (1, 256), (64 * 196, 1024, 256): (0, None)}
     if grid_env is None and cus == 256 and (M, Cin, Kout) in small:
         want_sk, want_G = small[(M, Cin, Kout)]
