@@ -790,6 +790,44 @@ def test_random_legal_shapes(pkg, O, torch_dev):
         assert (got[:, ring, :] == 0).all(), (N, H, W, C, K)
 
 
+def test_residual_block_in_a_graph(pkg, O, torch_dev):
+    """The three launches of the bottleneck block captured into one HIP graph: the prepare calls
+    allocate every launch's stream-K scratch on the capture stream beforehand (an allocation inside
+    a capture is an error), the replayed graph gives the eager result bit for bit and the oracle's
+    to tolerance."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(808)
+    N, C4, Cm = 20, 1024, 256      # 1x1 1024->256 at N = 20 takes its split-K form, the 3x3 its stream-K tail
+    x = (rng.rand(N, 14, 14, C4) - 0.5).astype(np.float32)
+    w1 = ((rng.rand(C4, Cm) - 0.5) / np.sqrt(C4) * 4).astype(np.float32)
+    w2 = ((rng.rand(Cm, Cm, 3, 3) - 0.5) / np.sqrt(9 * Cm) * 4).astype(np.float32)
+    w3 = ((rng.rand(Cm, C4) - 0.5) / np.sqrt(Cm) * 4).astype(np.float32)
+    bn = [((rng.rand(c) - 0.5).astype(np.float32), (rng.rand(c) + 0.5).astype(np.float32)) for c in (Cm, Cm, C4)]
+    want = O.residual_block(x, w1, bn[0], w2, bn[1], w3, bn[2])
+    t = lambda a: _t(torch_dev, a)
+    xt, w1t, w3t = t(x), t(w1), t(w3)
+    U2 = pkg.filter_transform_f2(t(w2))
+    bnt = [(t(b), t(s)) for b, s in bn]
+    eager = pkg.residual_block(xt, w1t, bnt[0], U2, bnt[1], w3t, bnt[2]).clone()
+    assert O.rel_error(eager.cpu().numpy(), want) < TIGHT
+    out = torch.zeros_like(xt)
+    ws = torch.empty(pkg.lib().wino_residual_block_workspace_bytes(N, Cm) // 4, device=dev)
+    sg = torch.cuda.Stream()
+    with torch.cuda.stream(sg):
+        pkg.conv1x1_prepare(N * 196, C4, Cm)
+        pkg.conv3x3_prepare(N, Cm, Cm, 14, 14)
+        pkg.conv1x1_prepare(N * 196, Cm, C4)
+    sg.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=sg):
+        pkg.residual_block(xt, w1t, bnt[0], U2, bnt[1], w3t, bnt[2], out=out, workspace=ws)
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+
+
 # ------------------------------------------------------------------ errors
 def test_bad_shapes_raise(pkg, torch_dev):
     torch, dev = torch_dev
