@@ -4,6 +4,7 @@ reference's.  No GPU compute is attempted here."""
 import ctypes
 import os
 import re
+import shutil
 import subprocess
 
 import numpy as np
@@ -293,3 +294,22 @@ def test_launch_plan_rejects_bad_shapes(pkg):
     assert L.wino_conv3x3_plan(1, 14, 14, 16, 32, 256, *args) != 0      # K % 64
     assert L.wino_conv3x3_plan(1, 0, 14, 16, 64, 256, *args) != 0       # empty feature map
     assert L.wino_conv3x3_plan(1 << 20, 56, 56, 64, 64, 256, *args) != 0  # beyond 4 GiB
+
+
+@pytest.mark.parametrize("header", ["winograd_mi355x.h", "util.h", "Kernel128_winograd.h", "Kernel256_winograd.h",
+                                    "Kernel128_one.h", "Kernel256_one.h", "wino_data_files.h"])
+def test_public_headers_compile_alone_as_c99_and_cxx(header, tmp_path):
+    """A C host includes these headers with nothing else: each must be self-contained, strict C99
+    (no HIP, no C++-isms) and equally valid C++ (extern "C" guards)."""
+    inc = os.path.join(ROOT, "include")
+    if not os.path.exists(os.path.join(inc, header)):
+        pytest.skip(header + " not present")
+    for compiler, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++17", "cpp")):
+        cc = shutil.which(compiler)
+        if cc is None:
+            pytest.skip(compiler + " not available")
+        src = tmp_path / ("use_header." + ext)
+        src.write_text('#include "%s"\nint main(void) { return 0; }\n' % header)
+        out = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I" + inc, str(src)],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, (compiler, out.stderr[-1500:])
