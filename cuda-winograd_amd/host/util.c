@@ -1,5 +1,6 @@
 /* Host helpers of the ./Test driver -- see include/util.h for the contract and the
  * reference lines each function mirrors (util.c:5-63 of bssrdf/CUDA-Winograd). */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime under strict -std=c11 */
 #include "util.h"
 
 #include <errno.h>

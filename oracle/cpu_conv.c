@@ -22,6 +22,7 @@
  *   oracle_winograd_f4      the three reference launches BtdB -> OuterProduct -> AtIA
  *                           (Kernel128_winograd.cu:28-213) on [36][C][K] weights.
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime, pthreads under strict -std=c11 */
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
