@@ -369,7 +369,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       if (tid == 0)
         *(volatile unsigned*)smem = __hip_atomic_load(sk.tickets + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      finish = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem) == others;
+      finish = (unsigned)__builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem) == others;
     }
     if (!finish) {
       // slot 2lg for the segment that continues a tile (head of lg's range), 2lg+1 for the one that starts one
@@ -381,7 +381,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       if (tid == 0)      // ... before the workgroup's ticket
         *(volatile unsigned*)smem = __hip_atomic_fetch_add(sk.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      if (__builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem) != others) continue;   // someone else finishes the tile
+      if ((unsigned)__builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem) != others) continue;   // someone else finishes the tile
     }
     if (tid == 0)   // self-cleaning counter: the next launch finds 0 again
       __hip_atomic_store(sk.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
