@@ -191,10 +191,12 @@ static int sk_workspace(int dev, hipStream_t s, int G, size_t items, float** sla
 //     of straddling two items (one epilogue, not two).
 // Measured on MI355X (N = 128): 256 channels 392 items -> G = 256 (1 round + 17-iteration tail)
 // 125 us vs 151 us for two whole-item rounds; 128 channels 196 items -> G = 196, 43 us vs 51 us
-// for G = 256 (all tail).  An epilogue costs ~2.3 iterations, the tail's hand-off ~4.8.
+// for G = 256 (all tail).  An epilogue costs ~2.3 iterations, the tail's hand-off ~3.2.
 constexpr int SK_MIN_ITERS = 8, SK_ALIGNED_MIN_ITERS = 4;
 constexpr bool WINO_DEFAULT_FOUR_WAVES = false;
-constexpr double SK_EPILOGUE_ITERS = 2.3, SK_HANDOFF_ITERS = 4.8;
+// (hand-off refitted after the loop changes of this round: whole items vs the all-tail grid at 128 / 192 /
+//  256 / 384 channels, N = 46..100, solve to 2.7-3.6 iterations; it was 4.8)
+constexpr double SK_EPILOGUE_ITERS = 2.3, SK_HANDOFF_ITERS = 3.2;
 static double sk_cost(long long items, int nchunks, long long G) {
   const long long ndp = items / G, tail_items = items % G;
   double c = (double)ndp * (nchunks + SK_EPILOGUE_ITERS);
