@@ -50,7 +50,7 @@ constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-bloc
 constexpr int PF = 2;                        // filter-fragment prefetch distance (points); 2..6 measured equal
 constexpr int SLAB_BYTES = TB * 4 * KB * 4;  // 65536: pre-BN output of one item (64 tiles x 2x2 px x 64 k)
 #ifndef WINO_DMA0
-#define WINO_DMA0 4   // tuned with tools/ablate_fused: 0..4 equal, 6 +1 %, 8 +4 %
+#define WINO_DMA0 4   // tools/ablate_fused, current loop: 0 / 2 / 4 / 6 / 8 give 42.7 / 42.5 / 42.45 / 42.5 / 42.7 cycles per MFMA
 #endif
 constexpr int DMA0 = WINO_DMA0;              // first point-step that issues an LDS-DMA piece
 
