@@ -21,6 +21,10 @@
 namespace wino {
 namespace gemm1x1 {
 
+#ifndef WINO_1X1_DMA0
+#define WINO_1X1_DMA0 4   // first step of a stage (of 14) that issues an LDS-DMA piece of the next one;
+                          // tools/ablate_1x1: 0 / 2 / 4 / 6 within 1 % on all four reference shapes, 8 up to +9 %
+#endif
 constexpr int BM = 112;
 constexpr int WINO_INTERNAL_NO_BN = 1 << 16;   // not part of the public flag set
 constexpr int RB = BM / 16;  // 7 row blocks
@@ -308,9 +312,9 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
 #pragma unroll
         for (int j = 0; j < 4; j++) b[s + 1][j] = *(const float*)(st + b_off + (16 * (s + 1) + j) * BN * 4);
       }
-      // this wave's LDS-DMA pieces for the next stage, one per step from step 4 on
-      if (t >= 4 && t - 4 < PIECES) {
-        if (more) issue_piece(PAR ^ 1, a_soff, b_soff, t - 4);
+      // this wave's LDS-DMA pieces for the next stage, one per step from step WINO_1X1_DMA0 on
+      if (t >= WINO_1X1_DMA0 && t - WINO_1X1_DMA0 < PIECES) {
+        if (more) issue_piece(PAR ^ 1, a_soff, b_soff, t - WINO_1X1_DMA0);
       }
       __builtin_amdgcn_sched_barrier(0);
       wait_lds1(G::wait_count(t));
