@@ -287,8 +287,9 @@ static int check_conv3x3(int N, int H, int W, int C, int K) {
 // Two kernels, same arithmetic: the throughput kernel (64-tile x 64-out-channel items, 8-wave
 // workgroups, whole-item rounds + stream-K tail) and the one-wave-per-SIMD latency kernel (16 tiles
 // x 16 out-channels per workgroup; 14x14 maps only), which wins exactly while its grid fits one
-// round of the CUs: measured 14-15 us vs 27 us (128 channels, N <= 8) and 19-20 us vs 29 us (256
-// channels, N <= 4), then 27-37 us vs 28-30 us as soon as it needs a second round.
+// round of the CUs: measured at 64 / 128 / 192 / 256 / 384 / 512 channels, N = 1..24, the rule picks
+// the faster kernel at every point (e.g. 128 channels 14-15 us vs 20 up to N = 10, then 27 vs 20.7;
+// 256 channels 19-20 us vs 23-25 up to N = 5, then 36 vs 25.6).
 // WINO_3X3_ALGO=big|small overrides.
 static bool use_small_kernel(int N, int H, int W, int C, int K) {
   if (H != WINO_PQ || W != WINO_PQ) return false;
