@@ -10,11 +10,11 @@ HOST    := $(PKG)/host
 BUILD   := build
 
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function
-CFLAGS   := -O2 -fPIC -std=gnu11 -Iinclude -Wall
+CFLAGS   := -O2 -fPIC -std=gnu11 -Iinclude -I$(HOST) -Wall
 
 HIP_SRCS := $(wildcard $(CSRC)/*.hip)
 HIP_OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIP_SRCS))
-HOST_OBJS := $(BUILD)/util.o $(BUILD)/layer_driver.o
+HOST_OBJS := $(BUILD)/util.o $(BUILD)/layer_driver.o $(BUILD)/cpu_baseline.o
 
 LIB := $(PKG)/libwinograd_mi355x.so
 
@@ -26,7 +26,8 @@ $(BUILD):
 $(BUILD)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/winograd_mi355x.h | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(BUILD)/%.o: $(HOST)/%.c include/winograd_mi355x.h include/util.h | $(BUILD)
+$(BUILD)/cpu_baseline.o: CFLAGS := -O3 -march=x86-64-v3 -fPIC -std=gnu11 -Iinclude -I$(HOST) -Wall
+$(BUILD)/%.o: $(HOST)/%.c $(wildcard include/*.h) $(wildcard $(HOST)/*.h) | $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIB): $(HIP_OBJS) $(HOST_OBJS)

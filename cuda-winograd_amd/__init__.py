@@ -36,7 +36,10 @@ ABI_SYMBOLS = [
     "wino_conv3x3_direct", "wino_conv1x1_bn", "wino_conv1x1_bn_ex", "wino_conv1x1_direct",
     "wino_residual_block", "wino_residual_block_workspace_bytes", "wino_driver_set_batch",
     "wino_driver_set_gpus", "wino_driver_set_quiet", "wino_driver_get_batch",
-    "wino_driver_get_gpus", "wino_driver_last_result",
+    "wino_driver_get_gpus", "wino_driver_last_result", "wino_driver_last_output", "wino_driver_pack_times",
+    "wino_driver_set_gpu_alias", "wino_driver_set_stdout_compat", "wino_driver_get_stdout_compat",
+    "wino_driver_cpu_baseline", "wino_last_status_name", "wino_debug_reload_knobs",
+    "wino_residual_block_prepare", "wino_residual_block_prepare_hw", "wino_diag_conv3x3_clock",
     # reference entry points + helpers (Kernel*.h, util.h)
     "kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in",
     "kernel_256_1_out", "get_parameter", "transpose", "getTimeMicroseconds64", "output_checker",
@@ -53,6 +56,11 @@ class DriverResult(ctypes.Structure):
                 ("max_abs_err", ctypes.c_double), ("max_rel_err", ctypes.c_double),
                 ("error_cnt", c_long), ("flops", ctypes.c_double), ("N", c_int), ("gpus", c_int),
                 ("steady_us", ctypes.c_double)]
+
+
+class CpuBaselineResult(ctypes.Structure):
+    _fields_ = [("us", ctypes.c_double), ("gflops", ctypes.c_double), ("threads", c_int), ("reps", c_int),
+                ("max_abs_diff", ctypes.c_double), ("max_rel_diff", ctypes.c_double)]
 
 
 _lib = None
@@ -103,6 +111,16 @@ def lib() -> ctypes.CDLL:
     L.wino_driver_set_batch.argtypes = [c_int]
     L.wino_driver_set_gpus.argtypes = [c_int]
     L.wino_driver_set_quiet.argtypes = [c_int]
+    L.wino_driver_set_gpu_alias.argtypes = [c_int]
+    L.wino_driver_set_stdout_compat.argtypes = [c_int]
+    L.wino_driver_pack_times.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+    L.wino_driver_last_output.restype = POINTER(ctypes.c_float)
+    L.wino_driver_last_output.argtypes = [POINTER(c_size_t)]
+    L.wino_driver_cpu_baseline.argtypes = [POINTER(CpuBaselineResult)]
+    L.wino_last_status_name.restype = c_char_p
+    L.wino_residual_block_prepare.argtypes = [c_int, c_int, c_int, c_void_p]
+    L.wino_residual_block_prepare_hw.argtypes = [c_int] * 5 + [c_void_p]
+    L.wino_diag_conv3x3_clock.argtypes = [fp] * 5 + [c_int] * 3 + [fp, POINTER(c_int), c_void_p]
     for name in ("kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out",
                  "kernel_256_1_in", "kernel_256_1_out"):
         getattr(L, name).restype = c_int
@@ -126,6 +144,27 @@ def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
 
 def _stream() -> c_void_p:
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _on_current_device(*tensors) -> None:
+    """The library launches on the CURRENT device's stream: every tensor must live there."""
+    cur = torch.cuda.current_device()
+    for t in tensors:
+        if t is not None and t.device.index != cur:
+            raise WinoError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: "
+                            "wrap the call in torch.cuda.device(...)")
+
+
+def _out(t: torch.Tensor, shape, name: str) -> torch.Tensor:
+    """A caller-supplied output / workspace: written by the kernel as is, so it must be exactly what
+    the kernel assumes (a wrong-sized or strided buffer would be an out-of-bounds GPU write)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
+        raise WinoError(f"{name} must be a float32 CUDA(HIP) tensor")
+    if not t.is_contiguous():
+        raise WinoError(f"{name} must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise WinoError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
 
 
 # --------------------------------------------------------------------------- operators
@@ -169,8 +208,9 @@ def conv3x3_bn_relu(inp: torch.Tensor, U: torch.Tensor, bn_bias: torch.Tensor,
         raise WinoError("U / bn vectors do not match C, K")
     if out is None:
         out = torch.empty((N, Hp, Wp, K), dtype=torch.float32, device=x.device)
-    elif tuple(out.shape) != (N, Hp, Wp, K) or not out.is_contiguous():
-        raise WinoError("out must be a contiguous [N][H+2][W+2][K] tensor")
+    else:
+        _out(out, (N, Hp, Wp, K), "out")
+    _on_current_device(x, U, b, s, out)
     if Hp == 16 and Wp == 16:
         _check(lib().wino_conv3x3_bn_relu(x.data_ptr(), U.data_ptr(), b.data_ptr(), s.data_ptr(),
                                           out.data_ptr(), N, C, K, int(relu), _stream()),
@@ -233,6 +273,9 @@ def conv1x1_bn(A: torch.Tensor, B: torch.Tensor, bn_bias: torch.Tensor, bn_scale
         raise WinoError("bn vectors do not match Kout")
     if out is None:
         out = torch.empty((M, Kout), dtype=torch.float32, device=a.device)
+    else:
+        _out(out, (M, Kout), "out")
+    _on_current_device(a, bm, b, s, out)
     _check(lib().wino_conv1x1_bn(a.data_ptr(), bm.data_ptr(), b.data_ptr(), s.data_ptr(),
                                  out.data_ptr(), M, Cin, Kout, int(relu), _stream()),
            "wino_conv1x1_bn")
@@ -240,6 +283,32 @@ def conv1x1_bn(A: torch.Tensor, B: torch.Tensor, bn_bias: torch.Tensor, bn_scale
 
 
 RELU, A_PADDED, C_PADDED, ADD_RESIDUAL = 1, 2, 4, 8  # WINO_* flag bits of wino_conv1x1_bn_ex
+
+
+def residual_block_prepare(N: int, C4: int, Cm: int, H: int = 14, W: int = 14) -> None:
+    """Allocate the scratch of residual_block's three launches for the current stream (before graph capture)."""
+    _check(lib().wino_residual_block_prepare_hw(int(N), int(H), int(W), int(C4), int(Cm), _stream()),
+           "wino_residual_block_prepare_hw")
+
+
+def conv3x3_clock_ghz(inp, U, bn_bias, bn_scale, out) -> float:
+    """Diagnostic: one launch of the 3x3 throughput kernel's stamped build (14x14 only); returns the
+    median over workgroups of the in-kernel clock, d(s_memtime) / d(s_memrealtime) * 0.1 GHz."""
+    x, U = _dev(inp, "inp"), _dev(U, "U")
+    b, s = _dev(bn_bias, "bn_bias"), _dev(bn_scale, "bn_scale")
+    N, C, K = int(x.shape[0]), int(x.shape[3]), int(b.numel())
+    _out(out, (N, 16, 16, K), "out")
+    _on_current_device(x, U, b, s, out)
+    stamps = torch.zeros(2 * 2048, dtype=torch.int64, device=x.device)
+    wgs = c_int(0)
+    _check(lib().wino_diag_conv3x3_clock(x.data_ptr(), U.data_ptr(), b.data_ptr(), s.data_ptr(), out.data_ptr(),
+                                         N, C, K, stamps.data_ptr(), ctypes.byref(wgs), _stream()),
+           "wino_diag_conv3x3_clock")
+    st = stamps[:2 * wgs.value].view(-1, 2).double().cpu()
+    ok = st[:, 1] > 0
+    if not bool(ok.any()):
+        raise WinoError("clock probe returned no stamps")
+    return float((st[ok, 0] / st[ok, 1]).median()) * 0.1
 
 
 def conv1x1_prepare(M: int, Cin: int, Kout: int) -> None:
@@ -278,9 +347,16 @@ def conv1x1_bn_ex(A, B, bn_bias, bn_scale, flags: int, residual=None, out=None, 
     if padded and M % (H * W):
         raise WinoError(f"padded layouts need M = N*{H}*{W}, got M={M}")
     r = _dev(residual, "residual") if residual is not None else None
+    if r is not None and r.numel() != M * Kout:
+        raise WinoError(f"residual must hold M*Kout = {M * Kout} values, got {r.numel()}")
     shape = (M // (H * W), H + 2, W + 2, Kout) if flags & C_PADDED else (M, Kout)
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=a.device)
+    elif out.numel() != M * Kout or flags & C_PADDED:
+        _out(out, shape, "out")
+    else:
+        _out(out, None, "out")   # unpadded: any contiguous view of M*Kout values ([M][Kout] or [N][H][W][Kout])
+    _on_current_device(a, bm, b, s, r, out)
     if padded and (H, W) != (14, 14):
         _check(lib().wino_conv1x1_bn_ex_hw(a.data_ptr(), bm.data_ptr(), b.data_ptr(), s.data_ptr(),
                                            r.data_ptr() if r is not None else None, out.data_ptr(),
@@ -307,8 +383,15 @@ def residual_block(x, w1, bn1, U2, bn2, w3, bn3, out=None, workspace=None) -> to
     need = lib().wino_residual_block_workspace_bytes_hw(N, H, W, Cm)
     if workspace is None:
         workspace = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    else:
+        _out(workspace, None, "workspace")
+        if workspace.numel() * 4 < need:
+            raise WinoError(f"workspace too small: {workspace.numel() * 4} bytes, need {need}")
     if out is None:
         out = torch.empty_like(x)
+    else:
+        _out(out, x.shape, "out")
+    _on_current_device(x, w1, w3, U2, out, workspace, *vecs)
     args = (x.data_ptr(), w1.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
             U2.data_ptr(), vecs[2].data_ptr(), vecs[3].data_ptr(),
             w3.data_ptr(), vecs[4].data_ptr(), vecs[5].data_ptr(), out.data_ptr())

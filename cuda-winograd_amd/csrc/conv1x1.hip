@@ -87,7 +87,7 @@ static inline bool four_waves(int Cin, int Kout) { return Kout <= 128 || Cin <= 
 // whoever arrives last): 1024->256 54 -> 19-25 us for N <= 16, 512->128 16-17 -> 11.5-13 us,
 // 256->1024 17 -> 13.5 us at N = 1; 128->512 (4 steps) always loses.  See the model in sk1_grid.
 //
-// Developer overrides, read per call so that tests can sweep the decomposition: WINO_1X1_SK=0 / 1
+// Developer overrides (wino_common.h Knobs: read once, wino_debug_reload_knobs() re-reads): WINO_1X1_SK=0 / 1
 // forces the plain / stream-K form (1: whenever a legal grid exists), WINO_1X1_SK_GRID=G sets the
 // number of ranges (rounded down to a multiple of 8 and of the column blocks, at most one range
 // per k-step).
@@ -97,17 +97,16 @@ struct Sk1Model { double a_plain, t_plain, e_tile, a_sk1, t_sk1, a_sk2, t_sk2; }
 constexpr Sk1Model SK1_MODEL_8W = {2.7, 1.555, 1.75, 12.0, 1.60, 13.0, 1.558};
 constexpr Sk1Model SK1_MODEL_4W = {3.8, 0.778, 0.7, 9.5, 0.89, 11.0, 0.816};
 static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_form) {
-  const char* f_env = getenv("WINO_1X1_SK");
-  const char* g_env = getenv("WINO_1X1_SK_GRID");
-  const int force = f_env && *f_env ? atoi(f_env) : -1;
+  const Knobs kn = knobs();
+  const int force = kn.sk_1x1;
   if (force == 0 || cus < 8 || tiles < 1) return 0;
   const long long U = tiles * nk;
   // G is a multiple of 8 (whole XCD groups) and of the column blocks per row tile (a range is
   // run by one workgroup per column block)
   long long step = 8;
   while (step % nblk) step += 8;
-  if (g_env && *g_env) {
-    long long G = atoll(g_env);
+  if (kn.sk_1x1_grid) {
+    long long G = kn.sk_1x1_grid;
     if (G > U) G = U;
     if (G > SK1_MAX_GRID) G = SK1_MAX_GRID;
     G -= G % step;
@@ -319,6 +318,18 @@ int wino_residual_block_hw(const float* x, const float* w1, const float* bn1Bias
   if (rc) return rc;
   return wino_conv1x1_bn_ex_hw(t2, w3, bn3Bias, bn3Scale, x, out, N, H, W, Cm, C4,
                                WINO_RELU | WINO_A_PADDED | WINO_ADD_RESIDUAL, s);
+}
+
+int wino_residual_block_prepare_hw(int N, int H, int W, int C4, int Cm, wino_stream_t s) {
+  if (N < 1 || H < 1 || W < 1) { set_error("bad N=%d H=%d W=%d", N, H, W); return WINO_E_SHAPE; }
+  const long M = (long)N * H * W;
+  if (int rc = wino_conv1x1_prepare(M, C4, Cm, s)) return rc;
+  if (int rc = wino_conv3x3_prepare_hw(N, H, W, Cm, Cm, s)) return rc;
+  return wino_conv1x1_prepare(M, Cm, C4, s);
+}
+
+int wino_residual_block_prepare(int N, int C4, int Cm, wino_stream_t s) {
+  return wino_residual_block_prepare_hw(N, WINO_PQ, WINO_PQ, C4, Cm, s);
 }
 
 size_t wino_residual_block_workspace_bytes_hw(int N, int H, int W, int Cm) {

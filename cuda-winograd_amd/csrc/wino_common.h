@@ -26,6 +26,16 @@ int hip_fail(hipError_t e, const char* what);
 int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, float** slabs, unsigned** tickets);
 int sk_scratch_release(hipStream_t s);   // wino_stream_destroy: the stream's scratch, on every device
 int device_cus(int dev, int* cus);
+// Developer knobs (WINO_* environment variables), read once per process at first use and cached;
+// wino_debug_reload_knobs() re-reads them (tests sweep the launch decompositions that way).
+struct Knobs {
+  int sk_grid;        // WINO_SK_GRID: logical workgroups of the 3x3 throughput kernel (0 = cost model)
+  int sk_min_iters;   // WINO_SK_MIN_ITERS: shortest stream-K range of the 3x3 kernel (0 = default)
+  int algo_3x3;       // WINO_3X3_ALGO: 0 automatic, 1 "big" (throughput kernel), 2 "small" (latency kernel)
+  int sk_1x1;         // WINO_1X1_SK: -1 automatic, 0 plain form, 1 stream-K whenever a legal grid exists
+  int sk_1x1_grid;    // WINO_1X1_SK_GRID: number of ranges (0 = model)
+};
+Knobs knobs();
 #define WINO_HIP(call)                                          \
   do {                                                          \
     hipError_t e_ = (call);                                     \

@@ -33,7 +33,6 @@
 // *source* address for the raw patches (the LDS destination of an LDS-DMA is lane-linear)
 // and baked into the packed filter layout for U.
 #include "wino_f2_small_kernel.h"
-#include "wino_f2_fused4_kernel.h"
 
 #include <atomic>
 #include <mutex>
@@ -193,7 +192,6 @@ static int sk_workspace(int dev, hipStream_t s, int G, size_t items, float** sla
 // 125 us vs 151 us for two whole-item rounds; 128 channels 196 items -> G = 196, 43 us vs 51 us
 // for G = 256 (all tail).  An epilogue costs ~2.3 iterations, the tail's hand-off ~3.2.
 constexpr int SK_MIN_ITERS = 8, SK_ALIGNED_MIN_ITERS = 4;
-constexpr bool WINO_DEFAULT_FOUR_WAVES = false;
 // (hand-off refitted after the loop changes of this round: whole items vs the all-tail grid at 128 / 192 /
 //  256 / 384 channels, N = 46..100, solve to 2.7-3.6 iterations; it was 4.8)
 constexpr double SK_EPILOGUE_ITERS = 2.3, SK_HANDOFF_ITERS = 3.2;
@@ -212,16 +210,9 @@ static double sk_cost(long long items, int nchunks, long long G) {
   }
   return c;
 }
-static int sk_grid_for(int cus, long long items, int nchunks, int* G);
-static int sk_grid(int dev, long long items, int nchunks, int* G) {
-  int cus = 0;
-  if (int rc = sk_cus(dev, &cus)) return rc;
-  return sk_grid_for(cus, items, nchunks, G);
-}
 static int sk_grid_for(int cus, long long items, int nchunks, int* G) {
-  const char* g_env = getenv("WINO_SK_GRID");        // developer overrides, read per call so that
-  const char* m_env = getenv("WINO_SK_MIN_ITERS");   // tests can sweep the decomposition
-  const int min_iters = m_env && atoi(m_env) > 0 ? atoi(m_env) : SK_MIN_ITERS;
+  const Knobs kn = knobs();   // developer overrides (cached; tests sweep the decomposition through them)
+  const int min_iters = kn.sk_min_iters > 0 ? kn.sk_min_iters : SK_MIN_ITERS;
   const long long T = items * nchunks;
   long long g = cus;
   if (g > T / min_iters) g = T / min_iters;
@@ -239,7 +230,7 @@ static int sk_grid_for(int cus, long long items, int nchunks, int* G) {
       break;
     }
   }
-  if (g_env && atoi(g_env) >= 1) g = atoi(g_env);
+  if (kn.sk_grid >= 1) g = kn.sk_grid;
   if (g > 16384) g = 16384;   // 2 * G slabs of 64 KB must stay below the 4 GiB a buffer descriptor spans
   *G = (int)g;
   return WINO_OK;
@@ -291,15 +282,13 @@ static int check_conv3x3(int N, int H, int W, int C, int K) {
 // the faster kernel at every point (e.g. 128 channels 14-15 us vs 20 up to N = 10, then 27 vs 20.7;
 // 256 channels 19-20 us vs 23-25 up to N = 5, then 36 vs 25.6).
 // WINO_3X3_ALGO=big|small overrides.
-static bool use_small_kernel(int N, int H, int W, int C, int K) {
+static bool use_small_kernel(int N, int H, int W, int C, int K, int cus) {
   if (H != WINO_PQ || W != WINO_PQ) return false;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) sk_cus(dev, &cus);
   const long small_grid = (long)((N * WINO_TILES + 15) / 16) * (K / 16);
-  const char* algo_env = getenv("WINO_3X3_ALGO");
+  const int algo = knobs().algo_3x3;
   bool small = small_grid <= cus && (C % 16) == 0;
-  if (algo_env && !strcmp(algo_env, "big")) small = false;
-  if (algo_env && !strcmp(algo_env, "small")) small = (C % 16) == 0;
+  if (algo == 1) small = false;
+  if (algo == 2) small = (C % 16) == 0;
   return small;
 }
 
@@ -311,13 +300,14 @@ static int conv3x3_prepare(int N, int H, int W, int C, int K, hipStream_t s) {
     if (N > step) N = (int)(step > 64 ? step - step % 64 : step);
   }
   if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
-  if (use_small_kernel(N, H, W, C, K)) return WINO_OK;
-  int dev = 0;
+  int dev = 0, cus = 0;
   WINO_HIP(hipGetDevice(&dev));
+  if (int rc = sk_cus(dev, &cus)) return rc;
+  if (use_small_kernel(N, H, W, C, K, cus)) return WINO_OK;
   const int nTB = (int)(((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + TB - 1) / TB);
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;
-  if (int rc = sk_grid(dev, (long long)items, C / BC, &G)) return rc;
+  if (int rc = sk_grid_for(cus, (long long)items, C / BC, &G)) return rc;
   float* slabs;
   unsigned* tickets;
   return sk_workspace(dev, s, G, items, &slabs, &tickets);
@@ -362,45 +352,72 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
                               float* out, int N, int H, int W, int C, int K, int relu, hipStream_t s) {
   if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
   const bool fixed14 = H == WINO_PQ && W == WINO_PQ;
-  if (use_small_kernel(N, H, W, C, K)) {
+  int dev = 0, cus = 0;   // one device query per launch; the CU count is cached per device
+  WINO_HIP(hipGetDevice(&dev));
+  if (int rc = sk_cus(dev, &cus)) return rc;
+  if (use_small_kernel(N, H, W, C, K, cus)) {
     const int nT16 = (N * WINO_TILES + 15) / 16;
     hipLaunchKernelGGL(wino_f2_small_kernel, dim3(nT16, K / 16), dim3(64 * SMALL_WAVES), 0, s, in, U,
                        bnBias, bnScale, out, N, C, K, relu);
     return launch_status("wino_f2_small_kernel");
   }
-  int dev = 0;
-  WINO_HIP(hipGetDevice(&dev));
   const unsigned tiles_x = (unsigned)((W + 1) / 2), tiles = (unsigned)((H + 1) / 2) * tiles_x;
   const int nTB = (int)(((long long)N * tiles + TB - 1) / TB);
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;
-  if (int rc = sk_grid(dev, (long long)items, C / BC, &G)) return rc;
+  if (int rc = sk_grid_for(cus, (long long)items, C / BC, &G)) return rc;
   float* slabs = nullptr;
   unsigned* tickets = nullptr;
   if (int rc = sk_workspace(dev, s, G, items, &slabs, &tickets)) return rc;
   const long long Tt = (long long)(items % (size_t)G) * (C / BC);   // the stream-K tail's iterations
   const Geo geo = {H + 2, W + 2, tiles, tiles_x, make_fastdiv(tiles), make_fastdiv(tiles_x)};
   const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
-                           geo, bnBias, bnScale, out, slabs, tickets};
+                           geo, bnBias, bnScale, out, slabs, tickets, nullptr};
   if (!fixed14) return launch_fused<true>(prm, G, dev, s);
-  // 14x14: two builds of the same algorithm, 8 waves x 256 registers (default) or the experimental
-  // 4 waves x 512 registers (one MFMA stream per SIMD); WINO_3X3_WAVES=4|8 overrides
-  const char* wv_env = getenv("WINO_3X3_WAVES");
-  const bool four = wv_env ? atoi(wv_env) == 4 : WINO_DEFAULT_FOUR_WAVES;
-  if (four) {
-    static std::atomic<unsigned long long> attr4_done{0};
-    if (!((attr4_done.load() >> (dev & 63)) & 1ull)) {
-      WINO_HIP(hipFuncSetAttribute((const void*)(fused4::wino_f2_fused4_kernel<0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-      attr4_done.fetch_or(1ull << (dev & 63));
-    }
-    hipLaunchKernelGGL((fused4::wino_f2_fused4_kernel<0>), dim3(G), dim3(fused4::NT4), LDS_BYTES, s, prm);
-    return launch_status("wino_f2_fused4_kernel");
-  }
   return launch_fused<false>(prm, G, dev, s);
 }
 
+// Diagnostic: the throughput kernel's stamped build (ABLATE = 16: s_memtime / s_memrealtime around
+// the main loop of every workgroup; the outputs are the product kernel's).  bench.py runs it right
+// after its timed region to report the clock the chip holds inside THIS kernel under sustained load.
+static int conv3x3_clock_probe(const float* in, const float* U, const float* bnBias, const float* bnScale,
+                               float* out, int N, int C, int K, unsigned long long* stamps, int* workgroups,
+                               hipStream_t s) {
+  if (!in || !U || !bnBias || !bnScale || !out || !stamps || !workgroups) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if (int rc = check_conv3x3(N, WINO_PQ, WINO_PQ, C, K)) return rc;
+  int dev = 0, cus = 0;
+  WINO_HIP(hipGetDevice(&dev));
+  if (int rc = sk_cus(dev, &cus)) return rc;
+  const int nTB = (int)(((long long)N * WINO_TILES + TB - 1) / TB);
+  const size_t items = (size_t)nTB * (K / KB);
+  int G = 0;
+  if (int rc = sk_grid_for(cus, (long long)items, C / BC, &G)) return rc;
+  if (G > 2048) { set_error("clock probe: grid %d exceeds the stamp buffer", G); return WINO_E_SHAPE; }
+  float* slabs = nullptr;
+  unsigned* tickets = nullptr;
+  if (int rc = sk_workspace(dev, s, G, items, &slabs, &tickets)) return rc;
+  const long long Tt = (long long)(items % (size_t)G) * (C / BC);
+  const Geo geo = {WINO_HW, WINO_HW, WINO_TILES, 7, make_fastdiv(WINO_TILES), make_fastdiv(7)};
+  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
+                           geo, bnBias, bnScale, out, slabs, tickets, stamps};
+  static std::atomic<unsigned long long> attr_done{0};
+  if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
+    WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<16, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_done.fetch_or(1ull << (dev & 63));
+  }
+  hipLaunchKernelGGL((wino_f2_fused_kernel<16, false>), dim3(G), dim3(NTHREADS), LDS_BYTES, s, prm);
+  *workgroups = G;
+  return launch_status("wino_f2_fused_kernel (stamped)");
+}
+
 extern "C" {
+
+int wino_diag_conv3x3_clock(const float* in, const float* U, const float* bnBias, const float* bnScale,
+                            float* out, int N, int C, int K, unsigned long long* stamps_dev,
+                            int* workgroups, wino_stream_t s) {
+  return conv3x3_clock_probe(in, U, bnBias, bnScale, out, N, C, K, stamps_dev, workgroups, (hipStream_t)s);
+}
 
 int wino_conv3x3_plan(int N, int H, int W, int C, int K, int cus, int* grid, int* rounds, long* tail_iters,
                       int* iters_per_item) {

@@ -132,24 +132,6 @@ __host__ __device__ inline unsigned sk_start(unsigned l, unsigned q, unsigned re
   return l * q + l * rem / G;
 }
 
-// In-quad exchange (lanes 4a..4a+3): value of lane ^ 1 / lane ^ 2, by DPP quad_perm.
-__device__ __forceinline__ float quad_xor1(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float quad_xor2(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
-}
-// 4x4 transpose across the 4 lanes of a quad: lane i holds a[0..3]; afterwards lane i holds
-// { a_of_lane0[i], a_of_lane1[i], a_of_lane2[i], a_of_lane3[i] }.  b0 / b1 = bit 0 / 1 of the lane.
-__device__ __forceinline__ f32x4 quad_transpose(f32x4 a, bool b0, bool b1) {
-  float s, r;
-  s = b0 ? a[0] : a[1]; r = quad_xor1(s); a[0] = b0 ? r : a[0]; a[1] = b0 ? a[1] : r;
-  s = b0 ? a[2] : a[3]; r = quad_xor1(s); a[2] = b0 ? r : a[2]; a[3] = b0 ? a[3] : r;
-  s = b1 ? a[0] : a[2]; r = quad_xor2(s); a[0] = b1 ? r : a[0]; a[2] = b1 ? a[2] : r;
-  s = b1 ? a[1] : a[3]; r = quad_xor2(s); a[1] = b1 ? r : a[1]; a[3] = b1 ? a[3] : r;
-  return a;
-}
-
 // The kernel's only argument.  The fields below the line are used by the epilogue alone: it
 // re-reads them from the kernarg segment each time instead of keeping ~20 scalar registers
 // (pointers + two buffer descriptors) alive across the main loop, which is out of SGPRs.
@@ -166,6 +148,7 @@ struct FusedParams {
   float* out;
   float* slabs;
   unsigned* tickets;
+  unsigned long long* dbg;     // diagnostic builds only (ABLATE & (16 | 2048)): where the stamps go
 };
 
 template <int ABLATE, bool GEN = false>
@@ -805,11 +788,10 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #undef A_OFF
   wait_vmem_all();   // no LDS-DMA of this wave may land after the workgroup's LDS has been given away
 
-  // diagnostic builds: stamps go past the N images of `out` (the tool allocates that room)
+  // diagnostic builds: the stamps go to a buffer of their own (prm.dbg), never into an output
   if (ABLATE & 2048) {
     if (lane == 0) {
-      unsigned long long* dbg = (unsigned long long*)(prm.out + (size_t)N * WINO_HW * WINO_HW * K) +
-                                ((size_t)lg * 8 + w) * 8;
+      unsigned long long* dbg = prm.dbg + ((size_t)lg * 8 + w) * 8;
       dbg[0] = st_wait;
       dbg[1] = st_comp;
       dbg[2] = st_epi;
@@ -823,8 +805,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
     stamp_c += __builtin_amdgcn_s_memtime();
     stamp_r += __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
-      unsigned long long* dbg =
-          (unsigned long long*)(prm.out + (size_t)N * WINO_HW * WINO_HW * K) + (size_t)lg * 2;
+      unsigned long long* dbg = prm.dbg + (size_t)lg * 2;
       dbg[0] = stamp_c;
       dbg[1] = stamp_r;
     }

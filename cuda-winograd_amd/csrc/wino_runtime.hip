@@ -19,12 +19,21 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local hipError_t g_last_status = hipSuccess;
+
 int hip_fail(hipError_t e, const char* what) {
+  g_last_status = e;
   set_error("%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
   return WINO_E_HIP;
 }
 
 namespace {
+// One (device, stream)'s stream-K scratch.  Buffers are never freed or moved while the stream
+// lives: a HIP graph captured on the stream has the slab and ticket pointers baked into its
+// kernel arguments, and a launch may still be in flight when a larger shape arrives.  Growth
+// allocates a new, larger generation and parks the old one in `retired` until
+// wino_stream_destroy (sk_scratch_release); a graph captured against an old generation stays
+// valid -- launches on one stream serialise, and every launch returns its counters to zero.
 struct SkScratch {
   int dev;
   hipStream_t stream;
@@ -32,6 +41,7 @@ struct SkScratch {
   size_t slab_bytes;
   unsigned* tickets;
   size_t n_tickets;
+  std::vector<void*> retired;
 };
 std::mutex g_ws_mu;
 std::vector<SkScratch> g_ws;
@@ -43,22 +53,26 @@ int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, floa
   for (auto& e : g_ws)
     if (e.dev == dev && e.stream == s) ws = &e;
   if (!ws) {
-    g_ws.push_back(SkScratch{dev, s, nullptr, 0, nullptr, 0});
+    g_ws.push_back(SkScratch{dev, s, nullptr, 0, nullptr, 0, {}});
     ws = &g_ws.back();
   }
   if (ws->slab_bytes < slab_bytes) {
-    if (ws->slabs) { WINO_HIP(hipDeviceSynchronize()); WINO_HIP(hipFree(ws->slabs)); ws->slabs = nullptr; ws->slab_bytes = 0; }
     size_t n = (size_t)32 << 20;   // 32 MiB covers every reference shape on 256 CUs
     while (n < slab_bytes) n *= 2;
-    WINO_HIP(hipMalloc((void**)&ws->slabs, n));
+    float* fresh = nullptr;
+    WINO_HIP(hipMalloc((void**)&fresh, n));
+    if (ws->slabs) ws->retired.push_back(ws->slabs);
+    ws->slabs = fresh;
     ws->slab_bytes = n;
   }
   if (ws->n_tickets < n_tickets) {
-    if (ws->tickets) { WINO_HIP(hipDeviceSynchronize()); WINO_HIP(hipFree(ws->tickets)); ws->tickets = nullptr; ws->n_tickets = 0; }
     size_t n = 4096;
     while (n < n_tickets) n *= 2;
-    WINO_HIP(hipMalloc((void**)&ws->tickets, n * sizeof(unsigned)));
-    WINO_HIP(hipMemset(ws->tickets, 0, n * sizeof(unsigned)));
+    unsigned* fresh = nullptr;
+    WINO_HIP(hipMalloc((void**)&fresh, n * sizeof(unsigned)));
+    WINO_HIP(hipMemset(fresh, 0, n * sizeof(unsigned)));
+    if (ws->tickets) ws->retired.push_back(ws->tickets);
+    ws->tickets = fresh;
     ws->n_tickets = n;
   }
   *slabs = ws->slabs;
@@ -76,10 +90,44 @@ int sk_scratch_release(hipStream_t s) {
     WINO_HIP(hipSetDevice(g_ws[i].dev));
     if (g_ws[i].slabs) WINO_HIP(hipFree(g_ws[i].slabs));
     if (g_ws[i].tickets) WINO_HIP(hipFree(g_ws[i].tickets));
+    for (void* p : g_ws[i].retired) WINO_HIP(hipFree(p));
     g_ws.erase(g_ws.begin() + (long)i);
   }
   WINO_HIP(hipSetDevice(cur));
   return WINO_OK;
+}
+
+// ---- developer knobs: the environment is read ONCE per process (first use), not per launch.
+// Tests that sweep a knob change the environment and call wino_debug_reload_knobs().
+namespace {
+std::mutex g_knob_mu;
+std::atomic<bool> g_knobs_ready{false};
+Knobs g_knobs;
+int env_num(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+void read_knobs() {
+  Knobs k;
+  k.sk_grid = env_num("WINO_SK_GRID", 0);
+  k.sk_min_iters = env_num("WINO_SK_MIN_ITERS", 0);
+  const char* algo = getenv("WINO_3X3_ALGO");
+  k.algo_3x3 = algo && !strcmp(algo, "big") ? 1 : algo && !strcmp(algo, "small") ? 2 : 0;
+  k.sk_1x1 = env_num("WINO_1X1_SK", -1);
+  k.sk_1x1_grid = env_num("WINO_1X1_SK_GRID", 0);
+  g_knobs = k;
+}
+}  // namespace
+
+Knobs knobs() {
+  if (!g_knobs_ready.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lock(g_knob_mu);
+    if (!g_knobs_ready.load()) {
+      read_knobs();
+      g_knobs_ready.store(true, std::memory_order_release);
+    }
+  }
+  return g_knobs;
 }
 
 int device_cus(int dev, int* cus) {
@@ -102,6 +150,17 @@ extern "C" {
 int wino_abi_version(void) { return WINO_ABI_VERSION; }
 
 const char* wino_last_error_string(void) { return g_err; }
+
+// hipGetErrorName of the status the calling thread's most recent memcpy / synchronise wrapper got
+// from the runtime: the line the reference prints after each copy-back (Kernel128_winograd.cu:275,409).
+const char* wino_last_status_name(void) { return hipGetErrorName(g_last_status); }
+
+int wino_debug_reload_knobs(void) {
+  std::lock_guard<std::mutex> lock(g_knob_mu);
+  read_knobs();
+  g_knobs_ready.store(true, std::memory_order_release);
+  return WINO_OK;
+}
 
 int wino_device_count(int* count) {
   if (!count) return WINO_E_ARG;
@@ -141,21 +200,25 @@ int wino_memset(void* dptr, int value, size_t bytes) {
 }
 
 int wino_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  g_last_status = hipSuccess;
   WINO_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return WINO_OK;
 }
 
 int wino_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  g_last_status = hipSuccess;
   WINO_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return WINO_OK;
 }
 
 int wino_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+  g_last_status = hipSuccess;
   WINO_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
   return WINO_OK;
 }
 
 int wino_device_synchronize(void) {
+  g_last_status = hipSuccess;
   WINO_HIP(hipDeviceSynchronize());
   return WINO_OK;
 }

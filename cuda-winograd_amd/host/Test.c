@@ -12,9 +12,12 @@
  *     gpus   devices to split N over, no collective (default 1) [extension]
  *     iters  number of calls (default 100)                      [extension]
  *
- * After the reference's "Average Total Time" line a one-line JSON summary carries the
- * unclamped averages, effective TFLOP/s on the algorithmic (direct-convolution) FLOPs,
- * its fraction of the 157.3 TFLOP/s fp32 MFMA peak of one MI355X, and the error metrics.
+ * After the reference's "Average Total Time" line come a CPU-baseline line (the same layer as a
+ * naive im2col + SGEMM on the box's host cores, core count stated, diffed against the GPU output;
+ * BASELINE.md section 4) and a one-line JSON summary with the unclamped averages, effective
+ * TFLOP/s on the algorithmic (direct-convolution) FLOPs, its fraction of the 157.3 TFLOP/s fp32
+ * MFMA peak of one MI355X, and the error metrics.  WINO_STDOUT_COMPAT=1 prints the reference's
+ * exact lines instead ("cuDNN" labels, nothing extra); WINO_CPU_BASELINE=0 skips the CPU pass.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -66,8 +69,18 @@ int main(int argc, char** argv) {
     }
   }
   const int counted = nTest - 2;
-  printf("Average Total Time: [Mine: %d us], [Direct: %d us]\n", (int)(sum_mine / counted),
-         (int)(sum_cmp / counted));
+  const int compat = wino_driver_get_stdout_compat();
+  printf(compat ? "Average Total Time: [Mine: %d us], [cuDNN: %d us]\n"
+                : "Average Total Time: [Mine: %d us], [Direct: %d us]\n",
+         (int)(sum_mine / counted), (int)(sum_cmp / counted));
+  if (compat) return 0;   /* the reference prints nothing after this line (Test.c:50-55) */
+  const char* cb_env = getenv("WINO_CPU_BASELINE");
+  wino_cpu_baseline_result cb;
+  const int have_cb = !(cb_env && cb_env[0] == '0') && wino_driver_cpu_baseline(&cb) == WINO_OK;
+  if (have_cb)
+    printf("CPU baseline (naive im2col+SGEMM+BN, %d host threads, %d reps): %.0f us, %.1f GFLOP/s; "
+           "max |GPU - CPU| = %.3g (%.2g relative)\n",
+           cb.threads, cb.reps, cb.us, cb.gflops, cb.max_abs_diff, cb.max_rel_diff);
   us_mine /= counted;
   us_cmp /= counted;
   us_steady /= counted;
@@ -76,9 +89,13 @@ int main(int argc, char** argv) {
   printf("{\"layer\": \"%s\", \"N\": %d, \"gpus\": %d, \"iters\": %d, \"mine_us\": %.1f, "
          "\"comparator_us\": %.1f, \"effective_tflops\": %.3f, \"frac_of_fp32_mfma_peak\": %.4f, "
          "\"steady_us\": %.1f, \"steady_effective_tflops\": %.3f, \"steady_frac_of_fp32_mfma_peak\": %.4f, "
-         "\"max_abs_err\": %.6g, \"max_rel_err\": %.3g, \"error_cnt_1e-5\": %ld}\n",
+         "\"max_abs_err\": %.6g, \"max_rel_err\": %.3g, \"error_cnt_1e-5\": %ld, "
+         "\"cpu_baseline_us\": %.1f, \"cpu_baseline_gflops\": %.2f, \"cpu_threads\": %d, "
+         "\"gpu_vs_cpu_max_rel_diff\": %.3g}\n",
          LAYERS[mode].name, r.N, r.gpus, nTest, us_mine, us_cmp, tflops,
          tflops / (MI355X_FP32_MFMA_PEAK_TFLOPS * r.gpus), us_steady, tflops_steady,
-         tflops_steady / (MI355X_FP32_MFMA_PEAK_TFLOPS * r.gpus), worst_abs, worst_rel, worst_cnt);
+         tflops_steady / (MI355X_FP32_MFMA_PEAK_TFLOPS * r.gpus), worst_abs, worst_rel, worst_cnt,
+         have_cb ? cb.us : 0.0, have_cb ? cb.gflops : 0.0, have_cb ? cb.threads : 0,
+         have_cb ? cb.max_rel_diff : 0.0);
   return 0;
 }

@@ -14,8 +14,11 @@
  *     reference).  With G GPUs the batch is split contiguously, weights are replicated,
  *     one host thread drives each device and there is no inter-GPU communication; the
  *     reported time is (last finish - common start) over all devices;
- *   - both timers are clamped to 16 bits in the packed return value; exact numbers are
- *     available from wino_driver_last_result().
+ *   - the packed return value keeps `res >> 16` of Test.c:46 non-negative: the custom half is
+ *     clamped to 0x7FFF (32.8 ms), the comparator half to 0xFFFF; exact numbers are available
+ *     from wino_driver_last_result();
+ *   - wino_driver_cpu_baseline() times a naive im2col + SGEMM of the last call's layer on the
+ *     host cores (cpu_baseline.c) and diffs it against the GPU output: a reported baseline.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -27,6 +30,7 @@
 #include "Kernel128_winograd.h"
 #include "Kernel256_one.h"
 #include "Kernel256_winograd.h"
+#include "cpu_baseline.h"
 #include "util.h"
 #include "winograd_mi355x.h"
 
@@ -36,8 +40,18 @@
 #define STEADY_REPS 100
 
 /* ---------------------------------------------------------------- configuration */
-static int g_batch = 0, g_gpus = 0, g_quiet = -1;
+static int g_batch = 0, g_gpus = 0, g_quiet = -1, g_alias = -1, g_compat = -1;
 static wino_driver_result g_last;
+
+/* what the last kernel_*() call ran, kept for wino_driver_cpu_baseline() */
+static struct {
+  int kind, N, C, K, relu;
+  float *in, *w, *bias, *scale, *out;
+} g_kept;
+static void drop_kept(void) {
+  free(g_kept.in); free(g_kept.w); free(g_kept.bias); free(g_kept.scale); free(g_kept.out);
+  memset(&g_kept, 0, sizeof g_kept);
+}
 
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -61,6 +75,16 @@ static int quiet(void) {
 int wino_driver_set_batch(int N) { if (N < 1) return WINO_E_ARG; g_batch = N; return WINO_OK; }
 int wino_driver_set_gpus(int n) { if (n < 1 || n > MAX_GPUS) return WINO_E_ARG; g_gpus = n; return WINO_OK; }
 int wino_driver_set_quiet(int q) { g_quiet = q ? 1 : 0; return WINO_OK; }
+int wino_driver_set_gpu_alias(int on) { g_alias = on ? 1 : 0; return WINO_OK; }
+static int gpu_alias(void) {
+  if (g_alias < 0) g_alias = env_int("WINO_GPUS_ALIAS", 0) ? 1 : 0;
+  return g_alias;
+}
+int wino_driver_set_stdout_compat(int on) { g_compat = on ? 1 : 0; return WINO_OK; }
+int wino_driver_get_stdout_compat(void) {
+  if (g_compat < 0) g_compat = env_int("WINO_STDOUT_COMPAT", 0) ? 1 : 0;
+  return g_compat;
+}
 int wino_driver_last_result(wino_driver_result* r) { if (!r) return WINO_E_ARG; *r = g_last; return WINO_OK; }
 
 /* ---------------------------------------------------------------- small helpers */
@@ -110,7 +134,8 @@ typedef struct {
   int C, K, relu;
   const float *h_in, *h_w_wino, *h_w_cmp, *h_bias, *h_scale;
   float *h_out, *h_cmp;       /* this device's slices of the host outputs */
-  pthread_barrier_t* bar;
+  pthread_barrier_t* bar;     /* NULL: single job on the default stream, as the reference */
+  char status_mine[48], status_cmp[48];   /* hipGetErrorName of the two copy-backs */
   uint64_t t0_mine, t1_mine, t0_cmp, t1_cmp;
   double steady_us;           /* mean of STEADY_REPS back-to-back launches after the timed one */
 } job_t;
@@ -119,6 +144,11 @@ static void* job_main(void* arg) {
   job_t* j = (job_t*)arg;
   const int C = j->C, K = j->K, n = j->n;
   CK(wino_set_device(j->device));
+  /* several jobs (possibly aliased onto one device): each on its own stream -- the library's
+   * stream-K scratch is per (device, stream), and launches of one stream must not come from two threads */
+  wino_stream_t st = NULL;
+  if (j->bar) CK(wino_stream_create(&st));
+#define JOB_SYNC() (st ? wino_stream_synchronize(st) : wino_device_synchronize())
   float *d_in, *d_out, *d_bias, *d_scale, *d_w, *d_U = NULL, *d_cmp;
   const size_t in_elems = j->kind == 3 ? (size_t)n * HW * HW * C : (size_t)n * PQ * PQ * C;
   const size_t out_elems = j->kind == 3 ? (size_t)n * HW * HW * K : (size_t)n * PQ * PQ * K;
@@ -139,7 +169,7 @@ static void* job_main(void* arg) {
   CK(wino_memcpy_h2d(d_w, j->h_w_wino, w_elems * 4));
   if (j->kind == 3) {
     CK(wino_malloc((void**)&d_U, wino_filter_f2_elems(C, K) * 4));
-    CK(wino_filter_import_f4(d_w, d_U, C, K, NULL)); /* offline weight transform */
+    CK(wino_filter_import_f4(d_w, d_U, C, K, st)); /* offline weight transform */
   }
   CK(wino_device_synchronize());
 
@@ -147,10 +177,10 @@ static void* job_main(void* arg) {
   if (j->bar) pthread_barrier_wait(j->bar);
   j->t0_mine = getTimeMicroseconds64();
   if (j->kind == 3)
-    CK(wino_conv3x3_bn_relu(d_in, d_U, d_bias, d_scale, d_out, n, C, K, 1, NULL));
+    CK(wino_conv3x3_bn_relu(d_in, d_U, d_bias, d_scale, d_out, n, C, K, 1, st));
   else
-    CK(wino_conv1x1_bn(d_in, d_w, d_bias, d_scale, d_out, (long)n * PQ * PQ, C, K, j->relu, NULL));
-  CK(wino_device_synchronize());
+    CK(wino_conv1x1_bn(d_in, d_w, d_bias, d_scale, d_out, (long)n * PQ * PQ, C, K, j->relu, st));
+  CK(JOB_SYNC());
   j->t1_mine = getTimeMicroseconds64();
 
   /* extension: the same launch repeated back to back on warm caches / clocks (the first,
@@ -158,81 +188,104 @@ static void* job_main(void* arg) {
   {
     for (int r = 0; r < 20; ++r) {   /* untimed: lets the clocks ramp before the steady-state loop */
       if (j->kind == 3)
-        CK(wino_conv3x3_bn_relu(d_in, d_U, d_bias, d_scale, d_out, n, C, K, 1, NULL));
+        CK(wino_conv3x3_bn_relu(d_in, d_U, d_bias, d_scale, d_out, n, C, K, 1, st));
       else
-        CK(wino_conv1x1_bn(d_in, d_w, d_bias, d_scale, d_out, (long)n * PQ * PQ, C, K, j->relu, NULL));
+        CK(wino_conv1x1_bn(d_in, d_w, d_bias, d_scale, d_out, (long)n * PQ * PQ, C, K, j->relu, st));
     }
-    CK(wino_device_synchronize());
+    CK(JOB_SYNC());
     const uint64_t s0 = getTimeMicroseconds64();
     for (int r = 0; r < STEADY_REPS; ++r) {
       if (j->kind == 3)
-        CK(wino_conv3x3_bn_relu(d_in, d_U, d_bias, d_scale, d_out, n, C, K, 1, NULL));
+        CK(wino_conv3x3_bn_relu(d_in, d_U, d_bias, d_scale, d_out, n, C, K, 1, st));
       else
-        CK(wino_conv1x1_bn(d_in, d_w, d_bias, d_scale, d_out, (long)n * PQ * PQ, C, K, j->relu, NULL));
+        CK(wino_conv1x1_bn(d_in, d_w, d_bias, d_scale, d_out, (long)n * PQ * PQ, C, K, j->relu, st));
     }
-    CK(wino_device_synchronize());
+    CK(JOB_SYNC());
     j->steady_us = (double)(getTimeMicroseconds64() - s0) / STEADY_REPS;
   }
 
   /* 3. copy back */
-  CK(wino_memcpy_d2h(j->h_out, d_out, out_elems * 4));
+  {
+    const int rc = wino_memcpy_d2h(j->h_out, d_out, out_elems * 4);
+    snprintf(j->status_mine, sizeof j->status_mine, "%s", wino_last_status_name());
+    CK(rc);
+  }
 
   /* comparator on the same device and data */
   if (j->kind == 3) CK(wino_memcpy_h2d(d_w, j->h_w_cmp, wc_elems * 4));
-  CK(wino_device_synchronize());
+  CK(JOB_SYNC());
   if (j->bar) pthread_barrier_wait(j->bar);
   j->t0_cmp = getTimeMicroseconds64();
   if (j->kind == 3)
-    CK(wino_conv3x3_direct(d_in, d_w, d_bias, d_scale, d_cmp, n, C, K, 1, NULL));
+    CK(wino_conv3x3_direct(d_in, d_w, d_bias, d_scale, d_cmp, n, C, K, 1, st));
   else
-    CK(wino_conv1x1_direct(d_in, d_w, d_bias, d_scale, d_cmp, (long)n * PQ * PQ, C, K, j->relu, NULL));
-  CK(wino_device_synchronize());
+    CK(wino_conv1x1_direct(d_in, d_w, d_bias, d_scale, d_cmp, (long)n * PQ * PQ, C, K, j->relu, st));
+  CK(JOB_SYNC());
   j->t1_cmp = getTimeMicroseconds64();
-  CK(wino_memcpy_d2h(j->h_cmp, d_cmp, out_elems * 4));
+  {
+    const int rc = wino_memcpy_d2h(j->h_cmp, d_cmp, out_elems * 4);
+    snprintf(j->status_cmp, sizeof j->status_cmp, "%s", wino_last_status_name());
+    CK(rc);
+  }
 
   wino_free(d_in); wino_free(d_out); wino_free(d_cmp); wino_free(d_bias);
   wino_free(d_scale); wino_free(d_w); wino_free(d_U);
+  if (st) CK(wino_stream_destroy(st));
+#undef JOB_SYNC
   return NULL;
 }
 
 /* ---------------------------------------------------------------- one layer call */
-static int clamp16(uint64_t us) { return us > 0xFFFFu ? 0xFFFF : (int)us; }
+static int clamp_to(uint64_t us, int top) { return us > (uint64_t)top ? top : (int)us; }
 
-static int run_layer(int kind, int C, int K, int relu) {
+/* (mine << 16) | comparator as Kernel128_winograd.cu:433 builds it.  The custom half stops at
+ * 0x7FFF: Test.c:46 reads it back with a signed `res >> 16`. */
+int wino_driver_pack_times(uint64_t mine_us, uint64_t cmp_us) {
+  return (int)(((unsigned)clamp_to(mine_us, 0x7FFF) << 16) | (unsigned)clamp_to(cmp_us, 0xFFFF));
+}
+
+/* "hipSuccess" -> "cudaSuccess", "hipErrorX" -> "cudaErrorX" for WINO_STDOUT_COMPAT */
+static const char* compat_status(const char* hip_name, char* buf, size_t n) {
+  if (strncmp(hip_name, "hip", 3) == 0) snprintf(buf, n, "cuda%s", hip_name + 3);
+  else snprintf(buf, n, "%s", hip_name);
+  return buf;
+}
+
+/* the files of one layer: the name objects of the reference-compatible headers */
+typedef struct {
+  int kind, C, K, relu;
+  const char *in, *w_wino, *w_cmp, *bias, *scale;
+} layer_t;
+
+static int run_layer(const layer_t* ly) {
+  const int kind = ly->kind, C = ly->C, K = ly->K, relu = ly->relu;
   const int N = wino_driver_get_batch();
   int G = wino_driver_get_gpus();
   if (G > N) G = N;
   int have = 0;
   CK(wino_device_count(&have));
-  if (have < G) {
+  if (have < 1 || (have < G && !gpu_alias())) {
     printf("HIP failure: %d GPU(s) requested, %d visible\n", G, have);
     exit(EXIT_FAILURE);
   }
-  char name[256], name2[256];
+  char name2[256];
   float *h_in, *h_w_wino, *h_w_cmp, *h_bias, *h_scale;
   size_t in_per, out_per;
   if (kind == 3) {
-    snprintf(name, sizeof name, WINO_F_INPUT_3X3, C);
     snprintf(name2, sizeof name2, WINO_F_INPUT_3X3_BATCH, C, N);
     in_per = (size_t)HW * HW * C; out_per = (size_t)HW * HW * K;
-    h_in = load_batched(name, name2, (int)in_per, C, N);
-    snprintf(name, sizeof name, WINO_F_WEIGHT_WINOGRAD, C, K);
-    h_w_wino = get_parameter(name, 36 * C * K);
-    snprintf(name, sizeof name, WINO_F_WEIGHT_NCHW, C, K);
-    h_w_cmp = get_parameter(name, 9 * C * K);
-    snprintf(name, sizeof name, WINO_F_BN_BIAS_FOLDED, K);
-    h_bias = get_parameter(name, K);
-    snprintf(name, sizeof name, WINO_F_BN_SCALE_FOLDED, K);
-    h_scale = get_parameter(name, K);
+    h_in = load_batched(ly->in, name2, (int)in_per, C, N);
+    h_w_wino = get_parameter(ly->w_wino, 36 * C * K);
+    h_w_cmp = get_parameter(ly->w_cmp, 9 * C * K);
   } else {
     /* every 1x1 test reads a prefix of the _1024 files (Kernel128_one.cu:58-64) */
     in_per = (size_t)PQ * PQ * C; out_per = (size_t)PQ * PQ * K;
-    h_in = load_batched(WINO_F_ONE_INPUT, NULL, (int)in_per, C, N);
-    h_w_wino = get_parameter(WINO_F_ONE_WEIGHT, C * K);
+    h_in = load_batched(ly->in, NULL, (int)in_per, C, N);
+    h_w_wino = get_parameter(ly->w_wino, C * K);
     h_w_cmp = h_w_wino;
-    h_bias = get_parameter(WINO_F_ONE_BN_BIAS, K);
-    h_scale = get_parameter(WINO_F_ONE_BN_SCALE, K);
   }
+  h_bias = get_parameter(ly->bias, K);
+  h_scale = get_parameter(ly->scale, K);
   float* h_out = (float*)malloc(out_per * N * sizeof(float));
   float* h_cmp = (float*)malloc(out_per * N * sizeof(float));
   if (!h_out || !h_cmp) { printf("Bad Malloc\n"); exit(0); }
@@ -245,7 +298,7 @@ static int run_layer(int kind, int C, int K, int relu) {
     const int n0 = (int)((long)N * g / G), n1 = (int)((long)N * (g + 1) / G);
     job_t* j = &jobs[g];
     memset(j, 0, sizeof *j);
-    j->device = g; j->kind = kind; j->n0 = n0; j->n = n1 - n0;
+    j->device = g % have; j->kind = kind; j->n0 = n0; j->n = n1 - n0;
     j->C = C; j->K = K; j->relu = relu;
     j->h_in = h_in + in_per * n0; j->h_w_wino = h_w_wino; j->h_w_cmp = h_w_cmp;
     j->h_bias = h_bias; j->h_scale = h_scale;
@@ -258,13 +311,17 @@ static int run_layer(int kind, int C, int K, int relu) {
     for (int g = 0; g < G; ++g) pthread_create(&th[g], NULL, job_main, &jobs[g]);
     for (int g = 0; g < G; ++g) pthread_join(th[g], NULL);
     pthread_barrier_destroy(&bar);
+    CK(wino_set_device(0));
   }
   uint64_t s_m = jobs[0].t0_mine, e_m = jobs[0].t1_mine, s_c = jobs[0].t0_cmp, e_c = jobs[0].t1_cmp;
+  const char *st_m = jobs[0].status_mine, *st_c = jobs[0].status_cmp;
   for (int g = 1; g < G; ++g) {
     if (jobs[g].t0_mine < s_m) s_m = jobs[g].t0_mine;
     if (jobs[g].t1_mine > e_m) e_m = jobs[g].t1_mine;
     if (jobs[g].t0_cmp < s_c) s_c = jobs[g].t0_cmp;
     if (jobs[g].t1_cmp > e_c) e_c = jobs[g].t1_cmp;
+    if (strcmp(jobs[g].status_mine, "hipSuccess")) st_m = jobs[g].status_mine;
+    if (strcmp(jobs[g].status_cmp, "hipSuccess")) st_c = jobs[g].status_cmp;
   }
   const uint64_t mine_us = e_m - s_m, cmp_us = e_c - s_c;
 
@@ -295,10 +352,13 @@ static int run_layer(int kind, int C, int K, int relu) {
   free(interior);
 
   if (!quiet()) {
+    /* the reference's per-call lines (Kernel128_winograd.cu:270,275,404,409; util.c:62) */
+    char b1[64], b2[64];
+    const int compat = wino_driver_get_stdout_compat();
     printf("TotalTime = %d us\n", (int)mine_us);
-    printf("hipSuccess\n");
-    printf("Direct TotalTime = %d us\n", (int)cmp_us);
-    printf("hipSuccess\n");
+    printf("%s\n", compat ? compat_status(st_m, b1, sizeof b1) : st_m);
+    printf(compat ? "cuDNN TotalTime = %d us\n" : "Direct TotalTime = %d us\n", (int)cmp_us);
+    printf("%s\n", compat ? compat_status(st_c, b2, sizeof b2) : st_c);
     printf("[max_error: %f][error_cnt: %d]\n", max_err, (int)err_cnt);
   }
   memset(&g_last, 0, sizeof g_last);
@@ -314,15 +374,86 @@ static int run_layer(int kind, int C, int K, int relu) {
   for (int g = 1; g < G; ++g)
     if (jobs[g].steady_us > g_last.steady_us) g_last.steady_us = jobs[g].steady_us;
 
-  free(h_in); free(h_w_wino); if (h_w_cmp != h_w_wino) free(h_w_cmp);
-  free(h_bias); free(h_scale); free(h_out); free(h_cmp);
-  return (clamp16(mine_us) << 16) | clamp16(cmp_us);
+  /* keep what wino_driver_cpu_baseline() needs: inputs, direct-form weights, BN, the GPU output */
+  drop_kept();
+  g_kept.kind = kind; g_kept.N = N; g_kept.C = C; g_kept.K = K; g_kept.relu = relu;
+  g_kept.in = h_in; g_kept.w = h_w_cmp; g_kept.bias = h_bias; g_kept.scale = h_scale; g_kept.out = h_out;
+  if (h_w_wino != h_w_cmp) free(h_w_wino);
+  free(h_cmp);
+  return wino_driver_pack_times(mine_us, cmp_us);
+}
+
+const float* wino_driver_last_output(size_t* elems) {
+  if (elems) *elems = g_kept.out ? (size_t)g_kept.N * (g_kept.kind == 3 ? HW * HW : PQ * PQ) * g_kept.K : 0;
+  return g_kept.out;
+}
+
+/* ---------------------------------------------------------------- CPU baseline of the last call */
+int wino_driver_cpu_baseline(wino_cpu_baseline_result* r) {
+  if (!r) return WINO_E_ARG;
+  memset(r, 0, sizeof *r);
+  if (!g_kept.in) return WINO_E_ARG;   /* no kernel_*() call yet */
+  const int kind = g_kept.kind, N = g_kept.N, C = g_kept.C, K = g_kept.K;
+  const size_t out_per = (size_t)(kind == 3 ? HW * HW : PQ * PQ) * K;
+  float* cpu = (float*)malloc(out_per * N * sizeof(float));
+  if (!cpu) return WINO_E_ARG;
+  const int threads = wino_host_cores();
+  if (wino_cpu_conv(kind, g_kept.in, g_kept.w, g_kept.bias, g_kept.scale, cpu, N, C, K, g_kept.relu, threads)) {
+    free(cpu);   /* warm-up pass failed (malloc) */
+    return WINO_E_ARG;
+  }
+  int reps = 0;
+  const uint64_t t0 = getTimeMicroseconds64();
+  uint64_t t1;
+  do {
+    wino_cpu_conv(kind, g_kept.in, g_kept.w, g_kept.bias, g_kept.scale, cpu, N, C, K, g_kept.relu, threads);
+    ++reps;
+    t1 = getTimeMicroseconds64();
+  } while (t1 - t0 < 500000 && reps < 50);
+  double big = 0, diff = 0;
+  for (size_t i = 0; i < out_per * N; ++i) {
+    const double c = cpu[i], d = c - (double)g_kept.out[i];
+    if ((c < 0 ? -c : c) > big) big = c < 0 ? -c : c;
+    if ((d < 0 ? -d : d) > diff) diff = d < 0 ? -d : d;
+  }
+  free(cpu);
+  r->us = (double)(t1 - t0) / reps;
+  r->gflops = 2.0 * N * PQ * PQ * (double)K * C * (kind == 3 ? 9 : 1) / r->us * 1e-3;
+  r->threads = threads;
+  r->reps = reps;
+  r->max_abs_diff = diff;
+  r->max_rel_diff = big > 0 ? diff / big : 0;
+  return WINO_OK;
 }
 
 /* ---------------------------------------------------------------- the six entry points */
-int kernel_128(void) { return run_layer(3, 128, 128, 1); }
-int kernel_256(void) { return run_layer(3, 256, 256, 1); }
-int kernel_128_1_in(void) { return run_layer(1, 512, 128, 1); }   /* ReLU: Kernel128_one.cu:53 */
-int kernel_128_1_out(void) { return run_layer(1, 128, 512, 0); }  /* no ReLU: :271-272 */
-int kernel_256_1_in(void) { return run_layer(1, 1024, 256, 1); }  /* ReLU: Kernel256_one.cu:55 */
-int kernel_256_1_out(void) { return run_layer(1, 256, 1024, 0); } /* no ReLU: :273 */
+int kernel_128(void) {
+  static const layer_t ly = {3, 128, 128, 1, inputName128, weight_winograd_Name128, weight_NCHW_Name128,
+                             bnBias_winograd_Name128, bnScale_winograd_Name128};
+  return run_layer(&ly);
+}
+int kernel_256(void) {
+  static const layer_t ly = {3, 256, 256, 1, inputName256, weight_winograd_Name256, weight_NCHW_Name256,
+                             bnBias_winograd_Name256, bnScale_winograd_Name256};
+  return run_layer(&ly);
+}
+int kernel_128_1_in(void) {   /* ReLU: Kernel128_one.cu:53 */
+  static const layer_t ly = {1, 512, 128, 1, inputName128one, weightName128one, weightName128one,
+                             bnBias_myKernel_Name128one, bnScale_myKernel_Name128one};
+  return run_layer(&ly);
+}
+int kernel_128_1_out(void) {  /* no ReLU: Kernel128_one.cu:271-272 */
+  static const layer_t ly = {1, 128, 512, 0, inputName128one, weightName128one, weightName128one,
+                             bnBias_myKernel_Name128one, bnScale_myKernel_Name128one};
+  return run_layer(&ly);
+}
+int kernel_256_1_in(void) {   /* ReLU: Kernel256_one.cu:55 */
+  static const layer_t ly = {1, 1024, 256, 1, inputName256one, weightName256one, weightName256one,
+                             bnBias_myKernel_Name256one, bnScale_myKernel_Name256one};
+  return run_layer(&ly);
+}
+int kernel_256_1_out(void) {  /* no ReLU: Kernel256_one.cu:273 */
+  static const layer_t ly = {1, 256, 1024, 0, inputName256one, weightName256one, weightName256one,
+                             bnBias_myKernel_Name256one, bnScale_myKernel_Name256one};
+  return run_layer(&ly);
+}

@@ -44,7 +44,11 @@ extern "C" {
  * wino_conv3x3_bn_relu_hw, wino_conv3x3_direct_hw, wino_conv3x3_plan, wino_conv3x3_f4_*,
  * wino_conv1x1_prepare, wino_conv1x1_plan, wino_conv1x1_bn_ex_hw, wino_residual_block_hw,
  * wino_residual_block_workspace_bytes_hw; wino_stream_destroy now also releases the stream's
- * scratch; wino_conv3x3_bn_relu(_hw) take any batch (they used to reject tensors of 4 GiB). */
+ * scratch; wino_conv3x3_bn_relu(_hw) take any batch (they used to reject tensors of 4 GiB);
+ * wino_last_status_name, wino_debug_reload_knobs, wino_residual_block_prepare(_hw),
+ * wino_driver_set_gpu_alias, wino_driver_set_stdout_compat, wino_driver_cpu_baseline,
+ * wino_diag_conv3x3_clock.  The library-owned stream-K scratch is never freed or moved while its
+ * stream lives (it used to be reallocated when a larger shape arrived). */
 #define WINO_ABI_VERSION 1
 
 enum {
@@ -64,6 +68,10 @@ typedef void* wino_stream_t;
 /* ---- runtime plumbing (thin wrappers so that C hosts need no HIP headers) ---- */
 int wino_abi_version(void);
 const char* wino_last_error_string(void);
+/* hipGetErrorName() of the status the calling thread's most recent memcpy / synchronise wrapper got
+ * ("hipSuccess" when it worked): the line the reference prints after each copy-back,
+ * cudaGetErrorName(cudaMemcpy(...)) (Kernel128_winograd.cu:274-275,408-409). */
+const char* wino_last_status_name(void);
 int wino_device_count(int* count);
 int wino_set_device(int device);
 int wino_device_name(int device, char* buf, size_t buflen);
@@ -229,6 +237,11 @@ int wino_residual_block_hw(const float* x, const float* w1, const float* bn1Bias
                            int N, int H, int W, int C4, int Cm, void* workspace, size_t workspace_bytes,
                            wino_stream_t s);
 
+/* Allocates the library-owned scratch the block's three launches on stream `s` will use, ahead of a
+ * graph capture (the block's analogue of wino_conv3x3_prepare / wino_conv1x1_prepare). */
+int wino_residual_block_prepare(int N, int C4, int Cm, wino_stream_t s);
+int wino_residual_block_prepare_hw(int N, int H, int W, int C4, int Cm, wino_stream_t s);
+
 /* Independent comparator for the 1x1 layers: one thread per output, fp32 FMA loop. */
 int wino_conv1x1_direct(const float* A, const float* B, const float* bnBias,
                         const float* bnScale, float* C, long M, int Cin, int Kout, int relu,
@@ -255,6 +268,49 @@ typedef struct {
   double steady_us;      /* mean of 100 further back-to-back launches (warm), max over GPUs */
 } wino_driver_result;
 int wino_driver_last_result(wino_driver_result* r);
+/* The custom path's output of the last kernel_*() call, on the host: [N][16][16][K] (3x3, ring 0) or
+ * [N*196][Kout] (1x1); *elems receives the element count.  Valid until the next kernel_*() call.
+ * NULL before the first call.  (The reference keeps this in a local array, Kernel128_winograd.cu:257.) */
+const float* wino_driver_last_output(size_t* elems);
+/* The packed return value of the kernel_*() entry points, (mine << 16) | comparator
+ * (Kernel128_winograd.cu:433), with the custom half clamped to 0x7FFF and the comparator half to
+ * 0xFFFF so that the reference's signed decode `res >> 16`, `res & 0xFFFF` (Test.c:46-47) never
+ * sees a negative number. */
+int wino_driver_pack_times(uint64_t mine_us, uint64_t comparator_us);
+/* Developer knob (WINO_GPUS_ALIAS=1): job g of a multi-GPU call runs on device g % visible, so the
+ * threaded batch-split path (one host thread + one stream per job, common start barrier) can be
+ * exercised on a box with fewer GPUs than requested. */
+int wino_driver_set_gpu_alias(int on);
+/* WINO_STDOUT_COMPAT=1: the per-call lines carry the reference's exact labels -- "cuDNN TotalTime =
+ * %d us" and cuda-prefixed status names (Kernel128_winograd.cu:270-275,404-409) -- for scrapers written
+ * against the reference; ./Test then also prints "[cuDNN: %d us]" (Test.c:50-53) and nothing extra.
+ * The comparator behind that label is this library's direct-convolution kernel, not cuDNN. */
+int wino_driver_set_stdout_compat(int on);
+int wino_driver_get_stdout_compat(void);
+/* CPU baseline of the layer the LAST kernel_*() call ran (same inputs, same N): naive im2col +
+ * three-loop SGEMM + folded BN (+ReLU) on all host cores, timed with the wall clock (one warm-up,
+ * then repetitions for about half a second), and diffed against that call's GPU output.
+ * A reported baseline, never a fallback: nothing the library returns comes from it. */
+typedef struct {
+  double us;             /* mean wall time of one CPU pass over the layer */
+  double gflops;         /* algorithmic FLOPs / us */
+  int threads;           /* host threads used = cores this process may run on */
+  int reps;
+  double max_abs_diff;   /* max |GPU - CPU| over the valid outputs */
+  double max_rel_diff;   /* ... / max |CPU| */
+} wino_cpu_baseline_result;
+int wino_driver_cpu_baseline(wino_cpu_baseline_result* r);
+
+/* ---- diagnostics (measurement infrastructure, not part of the reference interface) -------------
+ * Re-reads the WINO_* developer knobs (the library reads them once per process). */
+int wino_debug_reload_knobs(void);
+/* The 3x3 throughput kernel's stamped build (same source, s_memtime / s_memrealtime around its main
+ * loop): runs one launch of it on `s` with the arguments of wino_conv3x3_bn_relu and writes one
+ * {shader cycles, 100 MHz ticks} pair per workgroup to stamps_dev (at least 2 * 2048 uint64).
+ * *workgroups receives the number of pairs.  in-kernel clock = cycles / ticks * 0.1 GHz.  14x14 only. */
+int wino_diag_conv3x3_clock(const float* in, const float* U, const float* bnBias, const float* bnScale,
+                            float* out, int N, int C, int K, unsigned long long* stamps_dev,
+                            int* workgroups, wino_stream_t s);
 
 #ifdef __cplusplus
 }

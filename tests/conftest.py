@@ -25,6 +25,30 @@ def pkg():
     return ge.load_package()
 
 
+class _Knobs:
+    """The library reads its WINO_* developer knobs once per process; tests that sweep them change the
+    environment through this helper, which makes the library re-read it (wino_debug_reload_knobs)."""
+
+    def __init__(self, monkeypatch, lib):
+        self._mp, self._lib = monkeypatch, lib
+
+    def set(self, name, value):
+        self._mp.setenv(name, str(value))
+        self._lib.wino_debug_reload_knobs()
+
+    def unset(self, name):
+        self._mp.delenv(name, raising=False)
+        self._lib.wino_debug_reload_knobs()
+
+
+@pytest.fixture
+def knobs(pkg, monkeypatch):
+    k = _Knobs(monkeypatch, pkg.lib())
+    yield k
+    monkeypatch.undo()
+    pkg.lib().wino_debug_reload_knobs()
+
+
 @pytest.fixture(scope="session")
 def O():
     from oracle import oracle

@@ -168,13 +168,13 @@ def _plan(pkg, N, H, W, C, K, cus):
     (32, 14, 14, 256, 256, 256), (1, 14, 14, 8, 64, 256), (128, 56, 56, 64, 64, 256),
     (128, 7, 7, 512, 512, 304), (5, 28, 28, 128, 192, 64), (17, 14, 14, 128, 256, 8), (3, 2, 2, 8, 64, 1),
 ])
-def test_launch_plan_covers_every_iteration_once(N, H, W, C, K, cus, pkg, monkeypatch):
+def test_launch_plan_covers_every_iteration_once(N, H, W, C, K, cus, pkg, knobs):
     """The throughput kernel's work decomposition, replayed on the host: `rounds` whole items per
     logical workgroup plus an evenly cut stream-K tail must cover every (item, chunk) iteration
     exactly once, never give one workgroup more than ceil(T/G) + a whole item's slack, and cut an
     item only inside the tail."""
-    monkeypatch.delenv("WINO_SK_GRID", raising=False)
-    monkeypatch.delenv("WINO_SK_MIN_ITERS", raising=False)
+    knobs.unset("WINO_SK_GRID")
+    knobs.unset("WINO_SK_MIN_ITERS")
     G, rounds, tail_iters, nch = _plan(pkg, N, H, W, C, K, cus)
     tiles = N * ((H + 1) // 2) * ((W + 1) // 2)
     items = -(-tiles // 64) * (K // 64)
@@ -217,18 +217,18 @@ def _plan1x1(pkg, M, Cin, Kout, cus):
     (196, 1024, 256, 256, None), (196, 512, 128, 256, None), (196, 256, 1024, 256, None), (196, 128, 512, 256, None),
     (32 * 196, 1024, 256, 256, None), (64 * 196, 1024, 256, 256, None),
 ])
-def test_one_by_one_plan_covers_every_step_once(M, Cin, Kout, cus, grid_env, pkg, monkeypatch):
+def test_one_by_one_plan_covers_every_step_once(M, Cin, Kout, cus, grid_env, pkg, knobs):
     """The 1x1 kernel's stream-K decomposition, replayed on the host the way the kernel walks it:
     every (tile, k-step) is computed exactly once, a range is cut into whole tiles plus at most one
     head and one tail segment, no two partial segments share a slab slot, every cut tile's
     segments come from consecutive ranges (what the finisher's gather assumes), and the ranges are
     balanced to one step.  The two facts DESIGN.md section 3.2 states for the reference layers."""
-    monkeypatch.delenv("WINO_1X1_SK", raising=False)
+    knobs.unset("WINO_1X1_SK")
     if grid_env is None:
-        monkeypatch.delenv("WINO_1X1_SK_GRID", raising=False)
+        knobs.unset("WINO_1X1_SK_GRID")
     else:
-        monkeypatch.setenv("WINO_1X1_SK", "1")
-        monkeypatch.setenv("WINO_1X1_SK_GRID", grid_env)
+        knobs.set("WINO_1X1_SK", "1")
+        knobs.set("WINO_1X1_SK_GRID", grid_env)
     G, nMB, nblk, nk, sk = _plan1x1(pkg, M, Cin, Kout, cus)
     assert nMB == -(-M // 112) and nk == Cin // 32 and Kout % nblk == 0 and Kout // nblk in (64, 128)
     tiles = nMB * nblk

@@ -212,7 +212,7 @@ def test_conv3x3_is_deterministic_under_load(pkg, torch_dev):
 
 
 @pytest.mark.parametrize("N,C,K", [(128, 256, 256), (40, 128, 128), (17, 64, 192), (9, 8, 64)])
-def test_conv3x3_streamk_decompositions_agree(N, C, K, pkg, O, torch_dev, monkeypatch):
+def test_conv3x3_streamk_decompositions_agree(N, C, K, pkg, O, torch_dev, knobs):
     """The throughput kernel splits T = items * C/8 chunk iterations evenly over G logical
     workgroups (stream-K); an item cut by a range boundary is finished by whichever workgroup
     draws its last ticket.  Every G must give the same values (to rounding: the cut points move
@@ -221,18 +221,18 @@ def test_conv3x3_streamk_decompositions_agree(N, C, K, pkg, O, torch_dev, monkey
     ranges (many whole items per workgroup), G = 2048 short ones (items cut into many segments,
     more workgroups than CUs: late workgroups find slabs published long before)."""
     torch, dev = torch_dev
-    monkeypatch.setenv("WINO_3X3_ALGO", "big")
+    knobs.set("WINO_3X3_ALGO", "big")
     rng = np.random.RandomState(5 + N)
     x, w, s, b = _rand_layer(rng, N, C, K)
     xt, wt, st, bt = (_t(torch_dev, a) for a in (x, w, s, b))
     U = pkg.filter_transform_f2(wt)
-    monkeypatch.delenv("WINO_SK_GRID", raising=False)
+    knobs.unset("WINO_SK_GRID")
     ref = pkg.conv3x3_bn_relu(xt, U, bt, st).clone()
     want = O.conv3x3_bn_relu_direct(x[:2], w, s, b)
     assert O.rel_error(ref[:2].cpu().numpy(), want) < TIGHT
     scale = float(ref.abs().max())
     for grid in (8, 24, 64, 136, 200, 256, 392, 2048):
-        monkeypatch.setenv("WINO_SK_GRID", str(grid))
+        knobs.set("WINO_SK_GRID", str(grid))
         a = pkg.conv3x3_bn_relu(xt, U, bt, st).clone()
         c = pkg.conv3x3_bn_relu(xt, U, bt, st)
         assert torch.equal(a, c), f"grid {grid}: not reproducible"
@@ -266,29 +266,6 @@ def test_conv3x3_other_feature_maps(N, H, W, C, K, pkg, O, torch_dev):
     ring = np.ones((H + 2, W + 2), bool)
     ring[1:H + 1, 1:W + 1] = False
     assert (got[:, ring, :] == 0).all()
-
-
-def test_conv3x3_four_wave_build(pkg, O, torch_dev, monkeypatch):
-    """The experimental one-wave-per-SIMD build of the throughput kernel (WINO_3X3_WAVES=4:
-    4 waves x 512 registers, accumulators in AGPRs) computes the same
-    function: oracle on a sample, the 8-wave build to rounding, bitwise reproducible."""
-    torch, dev = torch_dev
-    monkeypatch.setenv("WINO_3X3_ALGO", "big")
-    rng = np.random.RandomState(77)
-    N, C, K = 50, 128, 192
-    x, w, s, b = _rand_layer(rng, N, C, K)
-    xt, wt, st, bt = (_t(torch_dev, a) for a in (x, w, s, b))
-    U = pkg.filter_transform_f2(wt)
-    monkeypatch.setenv("WINO_3X3_WAVES", "8")
-    ref = pkg.conv3x3_bn_relu(xt, U, bt, st).clone()
-    monkeypatch.setenv("WINO_3X3_WAVES", "4")
-    got = pkg.conv3x3_bn_relu(xt, U, bt, st).clone()
-    again = pkg.conv3x3_bn_relu(xt, U, bt, st)
-    assert torch.equal(got, again)
-    assert float((got - ref).abs().max()) < 2e-6 * float(ref.abs().max())
-    idx = [0, 17, 49]
-    assert O.rel_error(got[idx].cpu().numpy(), O.conv3x3_bn_relu_direct(x[idx], w, s, b)) < TIGHT
-    assert (got.cpu().numpy()[:, _ring(), :] == 0).all()
 
 
 def test_conv3x3_streams_and_graph(pkg, O, torch_dev):
@@ -351,6 +328,32 @@ def test_comparator_is_independent_and_correct(pkg, O, torch_dev):
     assert O.rel_error(got, O.conv3x3_bn_relu_direct(x, w, s, b)) < TIGHT
 
 
+@pytest.mark.parametrize("C", [128, 256])
+def test_comparator_3x3_matches_golden(C, data_dir, pkg, O, golden_outputs, torch_dev):
+    """The comparator kernels stand in for cuDNN in ./Test's second timer and diff; they are checked
+    against the oracle at the reference's own Test-0 / Test-1 layers (golden vectors), so that
+    "agrees with the comparator" elsewhere in this suite means something."""
+    x = load_bin(data_dir, f"input_14_1_{C}.bin").reshape(1, 16, 16, C)
+    w = load_bin(data_dir, f"weight_NCHW_{C}_{C}.bin").reshape(C, C, 3, 3)
+    s = load_bin(data_dir, f"bnScale_winograd_{C}.bin")
+    b = load_bin(data_dir, f"bnBias_winograd_{C}.bin")
+    got = pkg.conv3x3_direct(*(_t(torch_dev, a) for a in (x, w, b, s))).cpu().numpy()
+    want = golden_outputs["kernel_128" if C == 128 else "kernel_256"]
+    assert O.rel_error(got[:, 1:15, 1:15, :].reshape(want.shape), want) < TIGHT
+    assert (got[:, _ring(), :] == 0).all()
+
+
+@pytest.mark.parametrize("name", ["kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in", "kernel_256_1_out"])
+def test_comparator_1x1_matches_golden(name, data_dir, pkg, O, golden_outputs, torch_dev):
+    Cin, Kout, relu = O.ONE_BY_ONE_LAYERS[name]
+    A = load_bin(data_dir, "input_one_14_1024.bin", 196 * Cin).reshape(196, Cin)
+    B = load_bin(data_dir, "weight_one_1024.bin", Cin * Kout).reshape(Cin, Kout)
+    s = load_bin(data_dir, "bnScale_myKernel_one_1024.bin", Kout)
+    b = load_bin(data_dir, "bnBias_myKernel_one_1024.bin", Kout)
+    got = pkg.conv1x1_direct(_t(torch_dev, A), _t(torch_dev, B), _t(torch_dev, b), _t(torch_dev, s), relu)
+    assert O.rel_error(got.cpu().numpy(), golden_outputs[name]) < TIGHT
+
+
 # ------------------------------------------------------------------ 1x1 layers
 @pytest.mark.parametrize("name", ["kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in", "kernel_256_1_out"])
 def test_one_by_one_golden(name, data_dir, pkg, O, golden_outputs, torch_dev):
@@ -411,7 +414,7 @@ def test_one_by_one_full_size(name, pkg, O, torch_dev):
 
 
 @pytest.mark.parametrize("M,Cin,Kout", [(196, 1024, 256), (1000, 512, 128), (3 * 196, 256, 1024), (2500, 128, 512), (113, 64, 64), (700, 256, 192)])
-def test_one_by_one_streamk_decompositions_agree(M, Cin, Kout, pkg, O, torch_dev, monkeypatch):
+def test_one_by_one_streamk_decompositions_agree(M, Cin, Kout, pkg, O, torch_dev, knobs):
     """The 1x1 kernel's stream-K form cuts tiles x k-steps into G equal ranges; a tile cut by a range
     boundary is finished by whichever workgroup draws its last ticket, which adds the segments'
     slabs in k order.  Every G must agree with the fp64 oracle and with the plain launch (to
@@ -426,17 +429,17 @@ def test_one_by_one_streamk_decompositions_agree(M, Cin, Kout, pkg, O, torch_dev
     b = ((rng.rand(Kout) - 0.5) * 4).astype(np.float32)
     At, Bt, bt, st = (_t(torch_dev, a) for a in (A, B, b, s))
     want = O.conv1x1_bn(A, B, b, s, True)
-    monkeypatch.setenv("WINO_1X1_SK", "0")
-    monkeypatch.delenv("WINO_1X1_SK_GRID", raising=False)
+    knobs.set("WINO_1X1_SK", "0")
+    knobs.unset("WINO_1X1_SK_GRID")
     plain = pkg.conv1x1_bn(At, Bt, bt, st, True).clone()
     assert O.rel_error(plain.cpu().numpy(), want) < TIGHT
     scale = float(plain.abs().max())
-    monkeypatch.setenv("WINO_1X1_SK", "1")
+    knobs.set("WINO_1X1_SK", "1")
     for grid in (None, 8, 16, 40, 104, 256, 512, 1000, 4096):
         if grid is None:
-            monkeypatch.delenv("WINO_1X1_SK_GRID", raising=False)
+            knobs.unset("WINO_1X1_SK_GRID")
         else:
-            monkeypatch.setenv("WINO_1X1_SK_GRID", str(grid))
+            knobs.set("WINO_1X1_SK_GRID", str(grid))
         a = pkg.conv1x1_bn(At, Bt, bt, st, True).clone()
         c = pkg.conv1x1_bn(At, Bt, bt, st, True)
         assert torch.equal(a, c), f"grid {grid}: not reproducible"
@@ -444,7 +447,7 @@ def test_one_by_one_streamk_decompositions_agree(M, Cin, Kout, pkg, O, torch_dev
         assert float((a - plain).abs().max()) < 4e-6 * scale, f"grid {grid}"
 
 
-def test_one_by_one_streamk_flags_and_graph(pkg, O, torch_dev, monkeypatch):
+def test_one_by_one_streamk_flags_and_graph(pkg, O, torch_dev, knobs):
     """Stream-K form under the chaining flags (padded A, padded C with its zero ring, residual before
     the ReLU), then captured into a HIP graph after wino_conv1x1_prepare (no allocation inside the
     capture) and replayed."""
@@ -460,9 +463,9 @@ def test_one_by_one_streamk_flags_and_graph(pkg, O, torch_dev, monkeypatch):
     Ap[:, 1:15, 1:15, :] = A
     want = O.conv1x1_bn(A.reshape(-1, Cin), B, b, s, True)
     want_res = np.maximum(O.conv1x1_bn(A.reshape(-1, Cin), B, b, s, False) + R, 0)
-    monkeypatch.setenv("WINO_1X1_SK", "1")
+    knobs.set("WINO_1X1_SK", "1")
     for grid in ("24", "200"):
-        monkeypatch.setenv("WINO_1X1_SK_GRID", grid)
+        knobs.set("WINO_1X1_SK_GRID", grid)
         out = torch.full((N, 16, 16, Kout), float("nan"), device=dev)
         pkg.conv1x1_bn_ex(_t(torch_dev, Ap), _t(torch_dev, B), _t(torch_dev, b), _t(torch_dev, s),
                           pkg.RELU | pkg.A_PADDED | pkg.C_PADDED, out=out)
@@ -473,7 +476,7 @@ def test_one_by_one_streamk_flags_and_graph(pkg, O, torch_dev, monkeypatch):
                                  pkg.RELU | pkg.ADD_RESIDUAL, residual=_t(torch_dev, R)).cpu().numpy()
         assert O.rel_error(got3, want_res) < TIGHT
     # graph capture on a side stream: scratch allocated by prepare, outside the capture
-    monkeypatch.setenv("WINO_1X1_SK_GRID", "200")
+    knobs.set("WINO_1X1_SK_GRID", "200")
     At, Bt, bt, st = (_t(torch_dev, a) for a in (A.reshape(-1, Cin), B, b, s))
     outg = torch.zeros(N * 196, Kout, device=dev)
     sg = torch.cuda.Stream()
@@ -624,6 +627,42 @@ def test_residual_block(N, C4, Cm, pkg, O, torch_dev):
     assert (want > 0).mean() > 0.2  # the test exercises both sides of the final ReLU
 
 
+def test_residual_block_config5_per_gpu_share(pkg, O, torch_dev):
+    """BASELINE configs[4] as one GPU of eight sees it: the 1024 -> 256 -> 256 -> 1024 bottleneck at
+    N = 128, where the three launches take the forms they take in bench.py (1x1 1024->256 stream-K,
+    3x3 whole-item rounds + stream-K tail, 1x1 256->1024 plain) -- each form is tested alone at N = 128
+    elsewhere, this is the chain.  Sampled images against the fp64 composition of the layer oracles,
+    every element against a chain of the comparator kernels."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(128)
+    N, C4, Cm = 128, 1024, 256
+    x = (rng.rand(N, 14, 14, C4) - 0.5).astype(np.float32)
+    w1 = ((rng.rand(C4, Cm) - 0.5) / np.sqrt(C4) * 4).astype(np.float32)
+    w2 = ((rng.rand(Cm, Cm, 3, 3) - 0.5) / np.sqrt(9 * Cm) * 4).astype(np.float32)
+    w3 = ((rng.rand(Cm, C4) - 0.5) / np.sqrt(Cm) * 4).astype(np.float32)
+    bn = [((rng.rand(c) - 0.5).astype(np.float32), (rng.rand(c) + 0.5).astype(np.float32)) for c in (Cm, Cm, C4)]
+    t = lambda a: _t(torch_dev, a)
+    bnt = [(t(a), t(b)) for a, b in bn]
+    xt, w1t, w2t, w3t = t(x), t(w1), t(w2), t(w3)
+    out = torch.full((N, 14, 14, C4), float("nan"), device=dev)
+    pkg.residual_block(xt, w1t, bnt[0], pkg.filter_transform_f2(w2t), bnt[1], w3t, bnt[2], out=out)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    idx = [0, 63, 127]
+    want = O.residual_block(x[idx], w1, bn[0], w2, bn[1], w3, bn[2])
+    assert O.rel_error(got[idx], want) < TIGHT
+    assert (want > 0).mean() > 0.2
+    # every element: the same block from the comparator kernels (direct 1x1, direct 3x3, direct 1x1) + skip
+    t1 = pkg.conv1x1_direct(xt.reshape(-1, C4), w1t, bnt[0][0], bnt[0][1], True)
+    t1p = torch.zeros((N, 16, 16, Cm), device=dev)
+    t1p[:, 1:15, 1:15, :] = t1.reshape(N, 14, 14, Cm)
+    t2p = pkg.conv3x3_direct(t1p, w2t, bnt[1][0], bnt[1][1], True)
+    t2 = t2p[:, 1:15, 1:15, :].reshape(-1, Cm)
+    t3 = pkg.conv1x1_direct(t2, w3t, bnt[2][0], bnt[2][1], False)
+    chain = torch.relu(t3.reshape(N, 14, 14, C4) + xt).cpu().numpy()
+    assert O.rel_error(got, chain) < TIGHT
+
+
 def test_conv3x3_batch_beyond_one_launch(pkg, O, torch_dev):
     """One launch addresses its tensors with 32-bit byte offsets (< 4 GiB each); the entry point takes
     any batch and cuts larger ones into launches of whole images.  5100 images of 56x56x64 are 4.4 GB
@@ -659,7 +698,7 @@ def test_conv3x3_batch_beyond_one_launch(pkg, O, torch_dev):
     torch.cuda.empty_cache()
 
 
-def test_streamk_scratch_is_never_stale(pkg, O, torch_dev, monkeypatch):
+def test_streamk_scratch_is_never_stale(pkg, O, torch_dev, knobs):
     """The hand-over slabs are the same memory in every launch, written by one workgroup and read
     by another, possibly on another XCD.  Launches that repeat the same inputs cannot tell a fresh
     slab from a line cached by an earlier launch; two different inputs alternated can: each result
@@ -673,11 +712,11 @@ def test_streamk_scratch_is_never_stale(pkg, O, torch_dev, monkeypatch):
     Bm = t((rng.rand(Cin, Kout) - 0.5).astype(np.float32))
     sc, bi = t((rng.rand(Kout) - 0.5).astype(np.float32)), t((rng.rand(Kout) - 0.5).astype(np.float32))
     As = [t(((rng.rand(M, Cin) - 0.5) * s).astype(np.float32)) for s in (1.0, 37.0)]
-    monkeypatch.setenv("WINO_1X1_SK", "0")
-    monkeypatch.delenv("WINO_1X1_SK_GRID", raising=False)
+    knobs.set("WINO_1X1_SK", "0")
+    knobs.unset("WINO_1X1_SK_GRID")
     plain = [pkg.conv1x1_bn(a, Bm, bi, sc, False).clone() for a in As]
-    monkeypatch.setenv("WINO_1X1_SK", "1")
-    monkeypatch.setenv("WINO_1X1_SK_GRID", "120")
+    knobs.set("WINO_1X1_SK", "1")
+    knobs.set("WINO_1X1_SK_GRID", "120")
     first = [None, None]
     for rep in range(12):
         i = rep & 1
@@ -688,14 +727,14 @@ def test_streamk_scratch_is_never_stale(pkg, O, torch_dev, monkeypatch):
         assert torch.equal(got, first[i]), (rep, i)
     # 3x3: every item cut into segments
     N, C, K = 9, 64, 128
-    monkeypatch.setenv("WINO_3X3_ALGO", "big")
+    knobs.set("WINO_3X3_ALGO", "big")
     w = (rng.rand(K, C, 3, 3) - 0.5).astype(np.float32)
     U = pkg.filter_transform_f2(t(w))
     s3, b3 = t((rng.rand(K) - 0.5).astype(np.float32)), t((rng.rand(K) - 0.5).astype(np.float32))
     xs = [t(((rng.rand(N, 16, 16, C) - 0.5) * s).astype(np.float32)) for s in (1.0, 53.0)]
-    monkeypatch.setenv("WINO_SK_GRID", "8")      # items / 8 whole-item rounds, short tail
+    knobs.set("WINO_SK_GRID", "8")      # items / 8 whole-item rounds, short tail
     whole = [pkg.conv3x3_bn_relu(x, U, b3, s3, relu=False).clone() for x in xs]
-    monkeypatch.setenv("WINO_SK_GRID", "200")    # more workgroups than items: everything is tail
+    knobs.set("WINO_SK_GRID", "200")    # more workgroups than items: everything is tail
     first = [None, None]
     for rep in range(12):
         i = rep & 1
@@ -706,7 +745,7 @@ def test_streamk_scratch_is_never_stale(pkg, O, torch_dev, monkeypatch):
         assert torch.equal(got, first[i]), (rep, i)
 
 
-def test_streams_created_and_destroyed_do_not_leak_scratch(pkg, O, torch_dev, monkeypatch):
+def test_streams_created_and_destroyed_do_not_leak_scratch(pkg, O, torch_dev, knobs):
     """The stream-K scratch is owned by the library per (device, stream); wino_stream_destroy gives
     it back.  Fifty short-lived C-ABI streams, a stream-K launch on each: results right, device
     memory where it was (one stream's scratch is 32 MiB; a leak would cost 1.6 GB)."""
@@ -721,8 +760,8 @@ def test_streams_created_and_destroyed_do_not_leak_scratch(pkg, O, torch_dev, mo
     At, Bt, bt, st = (_t(torch_dev, a) for a in (A, B, b, s))
     out = torch.empty(M, Kout, device=dev)
     want = O.conv1x1_bn(A, B, b, s, True)
-    monkeypatch.setenv("WINO_1X1_SK", "1")
-    monkeypatch.setenv("WINO_1X1_SK_GRID", "64")
+    knobs.set("WINO_1X1_SK", "1")
+    knobs.set("WINO_1X1_SK_GRID", "64")
     torch.cuda.synchronize()
     free0 = None
     for i in range(50):
@@ -743,7 +782,7 @@ def test_streams_created_and_destroyed_do_not_leak_scratch(pkg, O, torch_dev, mo
 
 
 # ------------------------------------------------------------------ random legal shapes
-def test_random_legal_shapes(pkg, O, torch_dev):
+def test_random_legal_shapes(pkg, O, torch_dev, knobs):
     """Seeded sweep over shapes the C-ABI declares legal (1x1: any M, Cin % 32, Kout % 64; 3x3: any
     N, H, W, C % 8, K % 64), each against the fp64 oracle on an output pre-filled with NaN: the
     corners between the hand-picked cases (a column count that is a multiple of 64 but not of
@@ -760,15 +799,15 @@ def test_random_legal_shapes(pkg, O, torch_dev):
         b = ((rng.rand(Kout) - 0.5) * 4).astype(np.float32)
         relu = bool(i & 1)
         if i % 2:
-            os.environ["WINO_1X1_SK"] = "1"
-            os.environ["WINO_1X1_SK_GRID"] = str(8 * int(rng.randint(1, 64)))
+            knobs.set("WINO_1X1_SK", "1")
+            knobs.set("WINO_1X1_SK_GRID", str(8 * int(rng.randint(1, 64))))
         try:
             out = torch.full((M, Kout), float("nan"), device=dev)
             pkg.conv1x1_bn(t(A), t(B), t(b), t(s), relu, out=out)
             got = out.cpu().numpy()
         finally:
-            os.environ.pop("WINO_1X1_SK", None)
-            os.environ.pop("WINO_1X1_SK_GRID", None)
+            knobs.unset("WINO_1X1_SK")
+            knobs.unset("WINO_1X1_SK_GRID")
         assert np.isfinite(got).all(), (M, Cin, Kout)
         assert O.rel_error(got, O.conv1x1_bn(A, B, b, s, relu)) < TIGHT, (M, Cin, Kout)
     for i in range(16):
@@ -875,7 +914,7 @@ def test_entry_points_batched_via_abi(data_dir, pkg):
         assert L.wino_driver_last_result(ctypes.byref(res)) == 0
         assert res.N == 16 and res.gpus == 1
         assert res.max_rel_err < TIGHT and res.max_abs_err < 1e-4
-        assert (packed >> 16) == min(int(res.mine_us), 0xFFFF)
+        assert (packed >> 16) == min(int(res.mine_us), 0x7FFF)
     finally:
         L.wino_driver_set_batch(1)
         L.wino_driver_set_quiet(0)

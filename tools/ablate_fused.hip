@@ -14,6 +14,7 @@ using namespace wino::fused;
 
 static float* g_slabs;
 static unsigned* g_tickets;
+static unsigned long long* g_dbg;   // stamps of the diagnostic builds
 static int g_waves = 8;    // argv[4]: 4 = the one-wave-per-SIMD build
 static int g_grid = 256;   // logical workgroups (argv[2]); 0 = one whole item per workgroup
 
@@ -31,7 +32,7 @@ float run(const float* in, const float* U, const float* b, const float* s, float
   const int grid = grid_for(N, K);
   CK(hipMemset(g_tickets, 0, 65536 * 4));   // ablated variants may leave tickets behind
   const unsigned items = (unsigned)nTB * (K / KB), Tt = (items % grid) * (C / 8);
-  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / grid), Tt / grid, Tt % grid, Geo{}, b, s, out, g_slabs, g_tickets};
+  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / grid), Tt / grid, Tt % grid, Geo{}, b, s, out, g_slabs, g_tickets, g_dbg};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; i++)
@@ -55,6 +56,7 @@ int main(int argc, char** argv) {
   if (argc > 4) g_waves = atoi(argv[4]);
   CK(hipMalloc(&g_slabs, (size_t)2 * 4096 * SLAB_BYTES));
   CK(hipMalloc(&g_tickets, 65536 * 4));
+  CK(hipMalloc(&g_dbg, (size_t)4096 * 64 * 8));
   std::vector<int> Ns = {1, 83, 128};
   const size_t maxN = 256;
   float *in, *U, *b, *s, *out;
@@ -73,7 +75,7 @@ int main(int argc, char** argv) {
     const double iters = (double)nTB * (K / KB) * (C / 8) / wgs;
     run<16>(in, U, b, s, out, 128, C, K, 3);
     std::vector<unsigned long long> st((size_t)wgs * 2);
-    CK(hipMemcpy(st.data(), out + (size_t)128 * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(st.data(), g_dbg, st.size() * 8, hipMemcpyDeviceToHost));
     double cyc = 0, rt = 0, cmax = 0;
     for (int i = 0; i < wgs; i++) { cyc += st[2 * i]; rt += st[2 * i + 1]; cmax = std::max(cmax, (double)st[2 * i]); }
     printf("%s C=%d grid=%d: %.1f / %.1f / %.1f us   loop+epilogues: %.1f cycles per MFMA per SIMD (slowest workgroup %.1f) at %.3f GHz\n",
@@ -109,7 +111,7 @@ int main(int argc, char** argv) {
     const double iters = (double)nTB * (K / KB) * (C / 8) / wgs;   // chunk iterations per workgroup
     run<16>(in, U, b, s, out, N, C, K, 3);
     std::vector<unsigned long long> st((size_t)wgs * 2);
-    CK(hipMemcpy(st.data(), out + (size_t)N * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(st.data(), g_dbg, st.size() * 8, hipMemcpyDeviceToHost));
     double cyc = 0, rt = 0, cmin = 1e30, cmax = 0;
     for (int i = 0; i < wgs; i++) { cyc += st[2 * i]; rt += st[2 * i + 1]; cmin = std::min(cmin, (double)st[2 * i]); cmax = std::max(cmax, (double)st[2 * i]); }
     printf("main loop, N=128: in-kernel clock %.3f GHz; cycles per WG pass mean %.0f min %.0f max %.0f (= %.1f cycles per MFMA per SIMD)\n",
@@ -121,7 +123,7 @@ int main(int argc, char** argv) {
     const double iters = (double)nTB * (K / KB) * (C / 8) / wgs;
     run<2048>(in, U, b, s, out, N, C, K, 2);
     std::vector<unsigned long long> st((size_t)wgs * 64);
-    CK(hipMemcpy(st.data(), out + (size_t)N * 256 * K, st.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(st.data(), g_dbg, st.size() * 8, hipMemcpyDeviceToHost));
     double sum[8][7] = {{0}};
     for (int i = 0; i < wgs; i++) for (int w = 0; w < 8; w++) for (int k = 0; k < 7; k++) sum[w][k] += st[(i * 8 + w) * 8 + k];
     printf("per chunk iteration (%.2f per workgroup), mean over %d workgroups; stamps add overhead, read the SHARES:\n", iters, wgs);

@@ -573,7 +573,7 @@ wino_f2_fused4_kernel(const FusedParams prm) {
 
   if (ABLATE & 2048) {
     if (lane == 0) {
-      unsigned long long* dbg = (unsigned long long*)(prm.out + (size_t)N * WINO_HW * WINO_HW * K) +
+      unsigned long long* dbg = prm.dbg +
                                 ((size_t)lg * 8 + w) * 8;
       dbg[0] = st_wait;
       dbg[1] = st_comp;
@@ -585,8 +585,7 @@ wino_f2_fused4_kernel(const FusedParams prm) {
     stamp_c += __builtin_amdgcn_s_memtime();
     stamp_r += __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
-      unsigned long long* dbg =
-          (unsigned long long*)(prm.out + (size_t)N * WINO_HW * WINO_HW * K) + (size_t)lg * 2;
+      unsigned long long* dbg = prm.dbg + (size_t)lg * 2;
       dbg[0] = stamp_c;
       dbg[1] = stamp_r;
     }
