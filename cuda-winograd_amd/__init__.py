@@ -299,16 +299,17 @@ def conv3x3_clock_ghz(inp, U, bn_bias, bn_scale, out) -> float:
     N, C, K = int(x.shape[0]), int(x.shape[3]), int(b.numel())
     _out(out, (N, 16, 16, K), "out")
     _on_current_device(x, U, b, s, out)
-    stamps = torch.zeros(2 * 2048, dtype=torch.int64, device=x.device)
+    stamps = torch.zeros(4 * 2048, dtype=torch.int64, device=x.device)
     wgs = c_int(0)
     _check(lib().wino_diag_conv3x3_clock(x.data_ptr(), U.data_ptr(), b.data_ptr(), s.data_ptr(), out.data_ptr(),
                                          N, C, K, stamps.data_ptr(), ctypes.byref(wgs), _stream()),
            "wino_diag_conv3x3_clock")
-    st = stamps[:2 * wgs.value].view(-1, 2).double().cpu()
-    ok = st[:, 1] > 0
+    st = stamps[:4 * wgs.value].view(-1, 4).cpu()      # {cycles, 100 MHz ticks} at start and at end
+    cyc, ticks = (st[:, 2] - st[:, 0]).double(), (st[:, 3] - st[:, 1]).double()
+    ok = (ticks > 0) & (st[:, 1] != 0)
     if not bool(ok.any()):
         raise WinoError("clock probe returned no stamps")
-    return float((st[ok, 0] / st[ok, 1]).median()) * 0.1
+    return float((cyc[ok] / ticks[ok]).median()) * 0.1
 
 
 def conv1x1_prepare(M: int, Cin: int, Kout: int) -> None:

@@ -377,8 +377,8 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
   return launch_fused<false>(prm, G, dev, s);
 }
 
-// Diagnostic: the throughput kernel's stamped build (ABLATE = 16: s_memtime / s_memrealtime around
-// the main loop of every workgroup; the outputs are the product kernel's).  bench.py runs it right
+// Diagnostic: the throughput kernel's stamped build (ABLATE = 16: s_memtime / s_memrealtime at the start
+// and at the end of every workgroup's main loop, each pair stored at once; the outputs are the product kernel's).  bench.py runs it right
 // after its timed region to report the clock the chip holds inside THIS kernel under sustained load.
 static int conv3x3_clock_probe(const float* in, const float* U, const float* bnBias, const float* bnScale,
                                float* out, int N, int C, int K, unsigned long long* stamps, int* workgroups,

@@ -49,6 +49,9 @@ constexpr int LDS_BYTES = N_RSTAGE * RAW_BYTES + N_USTAGE * U_BYTES;  // 163840 
 constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
 constexpr int PF = 2;                        // filter-fragment prefetch distance (points); 2..6 measured equal
 constexpr int SLAB_BYTES = TB * 4 * KB * 4;  // 65536: pre-BN output of one item (64 tiles x 2x2 px x 64 k)
+#ifndef WINO_SCALAR_BTDB
+#define WINO_SCALAR_BTDB 0
+#endif
 #ifndef WINO_DMA0
 #define WINO_DMA0 4   // tools/ablate_fused, current loop: 0 / 2 / 4 / 6 / 8 give 42.7 / 42.5 / 42.45 / 42.5 / 42.7 cycles per MFMA
 #endif
@@ -243,8 +246,25 @@ wino_f2_fused_kernel(const FusedParams prm) {
   // B^T d B pieces (d, tmp, v are [row i][col j] = index 4i + j; Winograd point e = 4i + j), on
   // channel pairs (v_pk_add_f32)
   typedef f32x2 P2;
+#if WINO_SCALAR_BTDB
+  // experiment: plain v_sub_f32 / v_add_f32 pairs instead of v_pk_add_f32 (asm: the SLP vectoriser
+  // would fuse plain C++ back into packed ops)
+  auto sub2 = [](const P2& a, const P2& b) {
+    P2 r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.x));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.y));
+    return r;
+  };
+  auto add2 = [](const P2& a, const P2& b) {
+    P2 r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.x));
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.y));
+    return r;
+  };
+#else
   auto sub2 = [](const P2& a, const P2& b) { return a - b; };
   auto add2 = [](const P2& a, const P2& b) { return a + b; };
+#endif
   auto ld2 = [](const char* p) { return *(const f32x2*)p; };
   auto tmp_col = [&](P2* tmp, const P2* d, int j) {  // B^T d, column j
     tmp[0 * 4 + j] = sub2(d[0 * 4 + j], d[2 * 4 + j]);
@@ -260,7 +280,6 @@ wino_f2_fused_kernel(const FusedParams prm) {
     if (j == 3) v[e] = sub2(tmp[i * 4 + 1], tmp[i * 4 + 3]);
   };
 
-  unsigned long long stamp_c = 0, stamp_r = 0;
   unsigned long long st_wait = 0, st_comp = 0, st_epi = 0, st_prev = 0;   // ABLATE & 2048: phase stamps
   unsigned long long st_ph[4] = {0, 0, 0, 0};   // epilogue phases: barrier, A^T m A, slab+ticket, gather+finalize
   auto stamp = [&]() -> unsigned long long {
@@ -426,8 +445,13 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #pragma unroll
   for (int p = 0; p < 8; p++) a_lo[p] ^= RAW_BYTES;   // iteration 0 reads raw_1 from R1
   if (ABLATE & 16) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime)
-    stamp_c -= __builtin_amdgcn_s_memtime();
-    stamp_r -= __builtin_amdgcn_s_memrealtime();
+    // The start stamps go to memory at once: kept in SGPRs across the main loop (which has none to
+    // spare) they pushed loop-carried scalars into VGPRs and the build ran 15 % slower than the
+    // product kernel -- not a faithful probe of its clock.
+    if (tid == 0) {
+      prm.dbg[(size_t)lg * 4 + 0] = __builtin_amdgcn_s_memtime();
+      prm.dbg[(size_t)lg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
   }
 
   // One pipeline step = iteration `it`.  ONE instantiation: the raw stage that holds raw_{it+1}
@@ -802,12 +826,11 @@ wino_f2_fused_kernel(const FusedParams prm) {
     }
   }
   if (ABLATE & 16) {
-    stamp_c += __builtin_amdgcn_s_memtime();
-    stamp_r += __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
-      unsigned long long* dbg = prm.dbg + (size_t)lg * 2;
-      dbg[0] = stamp_c;
-      dbg[1] = stamp_r;
+      KernargPtr kp = kernarg();
+      unsigned long long* dbg = kp->dbg + (size_t)lg * 4;
+      dbg[2] = __builtin_amdgcn_s_memtime();
+      dbg[3] = __builtin_amdgcn_s_memrealtime();
     }
   }
 }

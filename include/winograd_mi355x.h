@@ -305,9 +305,10 @@ int wino_driver_cpu_baseline(wino_cpu_baseline_result* r);
  * Re-reads the WINO_* developer knobs (the library reads them once per process). */
 int wino_debug_reload_knobs(void);
 /* The 3x3 throughput kernel's stamped build (same source, s_memtime / s_memrealtime around its main
- * loop): runs one launch of it on `s` with the arguments of wino_conv3x3_bn_relu and writes one
- * {shader cycles, 100 MHz ticks} pair per workgroup to stamps_dev (at least 2 * 2048 uint64).
- * *workgroups receives the number of pairs.  in-kernel clock = cycles / ticks * 0.1 GHz.  14x14 only. */
+ * loop): runs one launch of it on `s` with the arguments of wino_conv3x3_bn_relu and writes four
+ * uint64 per workgroup to stamps_dev (at least 4 * 2048 uint64): {shader cycles, 100 MHz ticks} at the
+ * start of its main loop and the same pair at its end.  *workgroups receives the number of
+ * quadruples.  in-kernel clock = d(cycles) / d(ticks) * 0.1 GHz.  14x14 only. */
 int wino_diag_conv3x3_clock(const float* in, const float* U, const float* bnBias, const float* bnScale,
                             float* out, int N, int C, int K, unsigned long long* stamps_dev,
                             int* workgroups, wino_stream_t s);

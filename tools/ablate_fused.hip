@@ -1,7 +1,7 @@
 // Developer tool: prices the parts of the fused Winograd kernel by timing ablated variants
 // (see ABLATE in csrc/wino_f2_fused_kernel.h).  Not part of the library.
 //   hipcc --offload-arch=gfx950 -O3 -Iinclude -Icuda-winograd_amd/csrc tools/ablate_fused.hip -o tools/ablate_fused
-#include "wino_f2_fused4_kernel.h"
+#include "wino_f2_fused_kernel.h"
 
 #include <cstdlib>
 #include <algorithm>
@@ -15,7 +15,6 @@ using namespace wino::fused;
 static float* g_slabs;
 static unsigned* g_tickets;
 static unsigned long long* g_dbg;   // stamps of the diagnostic builds
-static int g_waves = 8;    // argv[4]: 4 = the one-wave-per-SIMD build
 static int g_grid = 256;   // logical workgroups (argv[2]); 0 = one whole item per workgroup
 
 static int grid_for(int N, int K) {
@@ -27,7 +26,6 @@ static int grid_for(int N, int K) {
 template <int AB>
 float run(const float* in, const float* U, const float* b, const float* s, float* out, int N, int C, int K, int reps) {
   CK(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<AB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  CK(hipFuncSetAttribute((const void*)(wino::fused4::wino_f2_fused4_kernel<AB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   const int nTB = (N * 49 + TB - 1) / TB;
   const int grid = grid_for(N, K);
   CK(hipMemset(g_tickets, 0, 65536 * 4));   // ablated variants may leave tickets behind
@@ -36,13 +34,11 @@ float run(const float* in, const float* U, const float* b, const float* s, float
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; i++)
-    if (g_waves == 4) hipLaunchKernelGGL((wino::fused4::wino_f2_fused4_kernel<AB>), dim3(grid), dim3(256), LDS_BYTES, 0, prm);
-    else hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < reps; i++)
-    if (g_waves == 4) hipLaunchKernelGGL((wino::fused4::wino_f2_fused4_kernel<AB>), dim3(grid), dim3(256), LDS_BYTES, 0, prm);
-    else hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
+    hipLaunchKernelGGL((wino_f2_fused_kernel<AB>), dim3(grid), dim3(NTHREADS), LDS_BYTES, 0, prm);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -53,7 +49,6 @@ float run(const float* in, const float* U, const float* b, const float* s, float
 int main(int argc, char** argv) {
   const int C = argc > 1 ? atoi(argv[1]) : 256, K = C;
   if (argc > 2) g_grid = atoi(argv[2]);
-  if (argc > 4) g_waves = atoi(argv[4]);
   CK(hipMalloc(&g_slabs, (size_t)2 * 4096 * SLAB_BYTES));
   CK(hipMalloc(&g_tickets, 65536 * 4));
   CK(hipMalloc(&g_dbg, (size_t)4096 * 64 * 8));
@@ -67,17 +62,34 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(U, h.data(), (size_t)16 * C * K * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b, h.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + K, K * 4, hipMemcpyHostToDevice));
+  if (argc > 3 && argv[3][0] == 'w') {  // per-workgroup pass times of the stamped build, with each range's shape
+    const int N = 128;
+    run<0>(in, U, b, s, out, N, C, K, 3000);
+    const int nTB = (N * 49 + TB - 1) / TB, wgs = grid_for(N, K), nch = C / 8;
+    const unsigned items = (unsigned)nTB * (K / KB), ndp = items / wgs, Tt = (items % wgs) * nch, q = Tt / wgs, rem = Tt % wgs;
+    run<16>(in, U, b, s, out, N, C, K, 20);
+    std::vector<unsigned long long> st((size_t)wgs * 4);
+    CK(hipMemcpy(st.data(), g_dbg, st.size() * 8, hipMemcpyDeviceToHost));
+    printf("lg cycles tail_begin tail_len segments(tail) straddles\n");
+    for (int l = 0; l < wgs; l++) {
+      const unsigned t0 = sk_start(l, q, rem, wgs), t1 = sk_start(l + 1, q, rem, wgs);
+      const int segs = t1 > t0 ? (int)((t1 - 1) / nch - t0 / nch + 1) : 0;
+      printf("%d %llu %u %u %d %d ndp=%u\n", l, st[4 * l + 2] - st[4 * l], t0, t1 - t0, segs, (int)(t0 % nch != 0) + (int)(t1 % nch != 0), ndp);
+    }
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 'q') {  // quick mode: just the product kernel at N = 128, three trials of 50 launches
+    run<0>(in, U, b, s, out, 128, C, K, 3000);   // clock ramp: ~0.4 s of the same kernel (see bench.py, preheat)
     float t[3];
-    for (int i = 0; i < 3; i++) t[i] = run<0>(in, U, b, s, out, 128, C, K, 50);
+    for (int i = 0; i < 3; i++) t[i] = run<0>(in, U, b, s, out, 128, C, K, 200);
     std::sort(t, t + 3);
     const int nTB = (128 * 49 + TB - 1) / TB, wgs = grid_for(128, K);
     const double iters = (double)nTB * (K / KB) * (C / 8) / wgs;
     run<16>(in, U, b, s, out, 128, C, K, 3);
-    std::vector<unsigned long long> st((size_t)wgs * 2);
+    std::vector<unsigned long long> st((size_t)wgs * 4);
     CK(hipMemcpy(st.data(), g_dbg, st.size() * 8, hipMemcpyDeviceToHost));
     double cyc = 0, rt = 0, cmax = 0;
-    for (int i = 0; i < wgs; i++) { cyc += st[2 * i]; rt += st[2 * i + 1]; cmax = std::max(cmax, (double)st[2 * i]); }
+    for (int i = 0; i < wgs; i++) { const double c = (double)(st[4 * i + 2] - st[4 * i]); cyc += c; rt += (double)(st[4 * i + 3] - st[4 * i + 1]); cmax = std::max(cmax, c); }
     printf("%s C=%d grid=%d: %.1f / %.1f / %.1f us   loop+epilogues: %.1f cycles per MFMA per SIMD (slowest workgroup %.1f) at %.3f GHz\n",
            argv[0], C, wgs, t[0], t[1], t[2], cyc / wgs / iters / 128.0, cmax / iters / 128.0, cyc / rt * 0.1);
     return 0;
@@ -110,10 +122,10 @@ int main(int argc, char** argv) {
     const int nTB = (N * 49 + TB - 1) / TB, wgs = grid_for(N, K);
     const double iters = (double)nTB * (K / KB) * (C / 8) / wgs;   // chunk iterations per workgroup
     run<16>(in, U, b, s, out, N, C, K, 3);
-    std::vector<unsigned long long> st((size_t)wgs * 2);
+    std::vector<unsigned long long> st((size_t)wgs * 4);
     CK(hipMemcpy(st.data(), g_dbg, st.size() * 8, hipMemcpyDeviceToHost));
     double cyc = 0, rt = 0, cmin = 1e30, cmax = 0;
-    for (int i = 0; i < wgs; i++) { cyc += st[2 * i]; rt += st[2 * i + 1]; cmin = std::min(cmin, (double)st[2 * i]); cmax = std::max(cmax, (double)st[2 * i]); }
+    for (int i = 0; i < wgs; i++) { const double c = (double)(st[4 * i + 2] - st[4 * i]); cyc += c; rt += (double)(st[4 * i + 3] - st[4 * i + 1]); cmin = std::min(cmin, c); cmax = std::max(cmax, c); }
     printf("main loop, N=128: in-kernel clock %.3f GHz; cycles per WG pass mean %.0f min %.0f max %.0f (= %.1f cycles per MFMA per SIMD)\n",
            cyc / rt * 0.1, cyc / wgs, cmin, cmax, cyc / wgs / iters / 128.0);
   }

@@ -34,6 +34,8 @@ def short(name):
                 if m:
                     a = [x.strip() for x in m.group(1).split(",")]
                     return "conv1x1_bn_kernel<%sw%s>" % (a[1] if len(a) > 1 else "?", ",streamK" if len(a) > 3 and a[3] in ("true", "1") else "")
+            if h == "wino_f2_fused_kernel" and re.search(r"wino_f2_fused_kernel<\s*16\s*,", name):
+                return "wino_f2_fused_kernel<stamped diagnostic build: bench.py's clock probe>"
             return h
     return None
 
@@ -108,7 +110,7 @@ for d in sorted(glob.glob(os.path.join(src, "*/"))):
     # dominant kernel of the config -> bench.py's roofline.traffic
     if "@" not in cfg and S["kernels"]:
         dom = DOMINANT.get(cfg) or max(S["kernels"], key=lambda k: S["kernels"][k].get("trace_avg_us", 0) * S["kernels"][k].get("calls", 0))
-        dk = next((k for k in S["kernels"] if dom in k), None)
+        dk = next((k for k in S["kernels"] if dom in k and "stamped" not in k), None)
         if dk and "hbm_bytes_per_launch" in S["kernels"][dk].get("derived", {}):
             d_ = S["kernels"][dk]["derived"]
             traffic[cfg] = {"kernel": dk, "hbm_bytes_per_launch": d_["hbm_bytes_per_launch"],
