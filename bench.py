@@ -83,6 +83,16 @@ def executed_mfma_flops(kind: str, N: int, C: int, K: int, H: int = 14) -> float
     return 2.0 * 16 * N * ((H + 1) // 2) ** 2 * C * K if kind == "3x3" else algorithmic_flops(kind, N, C, K)
 
 
+def plan_shard(scaling: str, batch: int, rank: int, world: int):
+    """(images this rank processes, images of the whole job).  weak: every rank owns `batch` images;
+    strong: the job's `batch` images are split contiguously, rank r takes shard_range(batch, r, world)
+    (the same split the C driver makes, layer_driver.c) -- no collective either way."""
+    if scaling == "strong":
+        n0, n1 = (batch * rank) // world, (batch * (rank + 1)) // world
+        return n1 - n0, batch
+    return batch, batch * world
+
+
 # ------------------------------------------------------------------ distributed plumbing
 def dist_env():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -232,13 +242,10 @@ def main():
 
     kind, C, K, relu = LAYERS[args.layer]
     H = FEATURE_MAP.get(args.layer, 14)
-    if args.scaling == "strong":     # a fixed global batch, split by image (no collective)
-        n0, n1 = pkg.shard_range(args.batch, rank, world)
-        N, global_batch = n1 - n0, args.batch
-        if N < 1:
-            raise SystemExit(f"--scaling strong: batch {args.batch} leaves rank {rank} of {world} without an image")
-    else:
-        N, global_batch = args.batch, args.batch * world
+    N, global_batch = plan_shard(args.scaling, args.batch, rank, world)
+    assert args.scaling != "strong" or (N == pkg.shard_range(args.batch, rank, world)[1] - pkg.shard_range(args.batch, rank, world)[0])
+    if N < 1:
+        raise SystemExit(f"--scaling strong: batch {args.batch} leaves rank {rank} of {world} without an image")
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     rnd = lambda *shape, scale=1.0: ((torch.rand(*shape, generator=g) - 0.5) * scale).to(dev)
     scale_v, bias_v = rnd(K), rnd(K)
@@ -323,13 +330,16 @@ def main():
         if t < elapsed:
             elapsed, kernel_ms = t, ev0.elapsed_time(ev1) / args.steps
 
-    # the clock the chip holds INSIDE the kernel, right after the timed region: a few launches of the
-    # stamped diagnostic build keep the load up, the last one is read
+    # the clock the chip holds INSIDE the kernel under the timed region's load: the stamped diagnostic
+    # build is queued directly behind another burst of product launches (no host synchronisation in
+    # between: an idle gap of a few hundred microseconds already lets the clock fall back, which is
+    # what a launch after a sync measures -- 2.05 GHz instead of 2.38 on the same box)
     clock_ghz = None
     if clock_probe is not None:
         try:
-            for _ in range(10):
-                clock_ghz = clock_probe()
+            for _ in range(max(args.steps, 100)):
+                step()
+            clock_ghz = clock_probe()
         except pkg.WinoError:
             clock_ghz = None
     flops_rank = algorithmic_flops(kind, N, C, K, H)
@@ -365,7 +375,8 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_source,
                      "clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
                      "clock_source": "in-kernel s_memtime / s_memrealtime of the stamped build of this kernel, "
-                                     "median over workgroups, launched right after the timed region"
+                                     "median over workgroups, queued directly behind a burst of product launches "
+                                     "after the timed region"
                                      if clock_ghz else None,
                      "kernel_us": round(kernel_ms * 1e3, 2),
                      "executed_mfma_frac": round(executed_mfma_flops(kind, N, C, K, H) /

@@ -67,3 +67,52 @@ def test_flop_accounting():
     assert abs(bench.algorithmic_flops("3x3", 128, 128, 128) - 7.399e9) < 0.001e9
     assert abs(bench.algorithmic_flops("1x1", 128, 1024, 256) - 13.15e9) < 0.01e9
     assert abs(bench.executed_mfma_flops("3x3", 128, 256, 256) - 13.15e9) < 0.01e9
+
+
+def test_bench_shard_plans(pkg):
+    """bench.py --scaling weak / strong: the per-rank batches and the job's FLOP accounting.  cfg 5 of
+    BASELINE.json (block, N = 1024 over 8 GPUs) is 128 images per rank either way."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert [bench.plan_shard("weak", 128, r, 8) for r in range(8)] == [(128, 1024)] * 8
+    assert [bench.plan_shard("strong", 1024, r, 8) for r in range(8)] == [(128, 1024)] * 8
+    # uneven strong split: contiguous, covers the batch once, equals the package's shard_range
+    for batch, world in ((130, 4), (7, 8), (128, 3)):
+        got = [bench.plan_shard("strong", batch, r, world) for r in range(world)]
+        assert sum(n for n, _ in got) == batch and all(g == batch for _, g in got)
+        for r in range(world):
+            a, b = pkg.shard_range(batch, r, world)
+            assert got[r][0] == b - a
+    # the whole job's FLOPs are the sum of the shards' (the kernel is linear in N)
+    kind, C, K, _ = bench.LAYERS["residual_block"]
+    per = sum(bench.algorithmic_flops(kind, bench.plan_shard("strong", 1024, r, 8)[0], C, K) for r in range(8))
+    assert abs(per - bench.algorithmic_flops(kind, 1024, C, K)) < 1.0
+    assert abs(bench.algorithmic_flops(kind, 1024, C, K) - 447.2e9) < 0.1e9     # BASELINE.md section 3
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("scaling,extra", [("weak", ["--layer", "conv3x3_256"]),
+                                           ("strong", ["--layer", "residual_block", "--batch", "64"])])
+def test_bench_two_ranks_on_one_gpu(scaling, extra, tmp_path):
+    """The multi-rank path of bench.py itself (process group, barrier, max over ranks, strong / weak
+    shards) rehearsed with two ranks sharing the one visible GPU over gloo -- the command the driver
+    launches for N GPUs, minus RCCL (which needs one device per rank)."""
+    import json
+    import subprocess
+    env = dict(os.environ, WINO_BENCH_BACKEND="gloo")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "5", "--warmup", "2", "--preheat-ms", "20", "--scaling", scaling,
+           "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 alone prints
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["scaling"] == scaling and js["value"] > 0
+    if scaling == "strong":
+        assert js["config"]["global_batch"] == 64 and js["config"]["per_gpu_batch"] == 32
+    else:
+        assert js["config"]["global_batch"] == 256 and js["config"]["per_gpu_batch"] == 128
