@@ -4,7 +4,7 @@
  * A deliberately naive convolution of the SAME layer on the SAME inputs: explicit im2col of a
  * block of output pixels, then a plain three-loop SGEMM against the [9C][K] (or [Cin][Kout])
  * weight matrix, then the folded BN (+ReLU).  Worker threads (one per online core) pull blocks of
- * 28 output pixels from a shared counter.  This is a reported baseline (SURVEY.md section 8d,
+ * up to 28 output pixels from a shared counter.  This is a reported baseline (SURVEY.md section 8d,
  * BASELINE.md section 4): it is timed and diffed against the GPU output, it never produces a
  * result the library returns.  It plays the part cuDNN's GEMM algorithm plays in the reference's
  * tables (README.md:25), on the box's own host cores.
@@ -18,7 +18,7 @@
 
 #include "cpu_baseline.h"
 
-enum { ROWS_PER_BLOCK = 28 };
+enum { MAX_ROWS_PER_BLOCK = 28 };
 
 typedef struct {
   int kind;                 /* 3 or 1 */
@@ -26,6 +26,7 @@ typedef struct {
   const float *in, *wmat, *bias, *scale;
   float* out;
   long rows;                /* N * 196 output pixels */
+  int rows_per_block;       /* 28, fewer when the layer has too few rows to give every thread some */
   atomic_long next_block;
 } work_t;
 
@@ -47,6 +48,7 @@ static void im2col_row(const work_t* w, long r, float* col) {
 static void* worker(void* arg) {
   work_t* w = (work_t*)arg;
   const int C = w->C, K = w->K, depth = w->kind == 3 ? 9 * C : C;
+  const int ROWS_PER_BLOCK = w->rows_per_block;
   float* cols = (float*)malloc((size_t)ROWS_PER_BLOCK * depth * sizeof(float));
   float* acc = (float*)malloc((size_t)ROWS_PER_BLOCK * K * sizeof(float));
   if (!cols || !acc) { free(cols); free(acc); return (void*)1; }
@@ -98,7 +100,7 @@ int wino_host_cores(void) {
 }
 
 int wino_cpu_conv(int kind, const float* in, const float* w, const float* bias, const float* scale,
-                  float* out, int N, int C, int K, int relu, int threads) {
+                  float* out, int N, int C, int K, int relu, int threads, int* threads_used) {
   if ((kind != 1 && kind != 3) || !in || !w || !bias || !scale || !out || N < 1 || C < 1 || K < 1) return -1;
   float* wmat = NULL;
   work_t wk;
@@ -120,6 +122,13 @@ int wino_cpu_conv(int kind, const float* in, const float* w, const float* bias, 
   atomic_init(&wk.next_block, 0);
   if (threads < 1) threads = 1;
   if (threads > 1024) threads = 1024;
+  {   /* blocks of up to 28 output pixels, at least ~4 per thread; never more threads than blocks */
+    long rpb = wk.rows / (4L * threads);
+    wk.rows_per_block = rpb < 1 ? 1 : rpb > MAX_ROWS_PER_BLOCK ? MAX_ROWS_PER_BLOCK : (int)rpb;
+    const long nblocks = (wk.rows + wk.rows_per_block - 1) / wk.rows_per_block;
+    if (threads > nblocks) threads = (int)nblocks;
+  }
+  if (threads_used) *threads_used = threads;
   pthread_t* th = (pthread_t*)malloc((size_t)threads * sizeof(pthread_t));
   int started = 0, rc = 0;
   if (!th) { free(wmat); return -1; }

@@ -398,7 +398,8 @@ int wino_driver_cpu_baseline(wino_cpu_baseline_result* r) {
   float* cpu = (float*)malloc(out_per * N * sizeof(float));
   if (!cpu) return WINO_E_ARG;
   const int threads = wino_host_cores();
-  if (wino_cpu_conv(kind, g_kept.in, g_kept.w, g_kept.bias, g_kept.scale, cpu, N, C, K, g_kept.relu, threads)) {
+  int used = threads;
+  if (wino_cpu_conv(kind, g_kept.in, g_kept.w, g_kept.bias, g_kept.scale, cpu, N, C, K, g_kept.relu, threads, &used)) {
     free(cpu);   /* warm-up pass failed (malloc) */
     return WINO_E_ARG;
   }
@@ -406,7 +407,7 @@ int wino_driver_cpu_baseline(wino_cpu_baseline_result* r) {
   const uint64_t t0 = getTimeMicroseconds64();
   uint64_t t1;
   do {
-    wino_cpu_conv(kind, g_kept.in, g_kept.w, g_kept.bias, g_kept.scale, cpu, N, C, K, g_kept.relu, threads);
+    wino_cpu_conv(kind, g_kept.in, g_kept.w, g_kept.bias, g_kept.scale, cpu, N, C, K, g_kept.relu, threads, NULL);
     ++reps;
     t1 = getTimeMicroseconds64();
   } while (t1 - t0 < 500000 && reps < 50);
@@ -419,7 +420,7 @@ int wino_driver_cpu_baseline(wino_cpu_baseline_result* r) {
   free(cpu);
   r->us = (double)(t1 - t0) / reps;
   r->gflops = 2.0 * N * PQ * PQ * (double)K * C * (kind == 3 ? 9 : 1) / r->us * 1e-3;
-  r->threads = threads;
+  r->threads = used;
   r->reps = reps;
   r->max_abs_diff = diff;
   r->max_rel_diff = big > 0 ? diff / big : 0;
