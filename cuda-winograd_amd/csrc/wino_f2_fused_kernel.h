@@ -78,9 +78,9 @@ __device__ __forceinline__ void wait_lds(int n) {
   }
 }
 // LDS requests issued at the top of pinned step q of the point loop (see the kernel): always 2
-// filter-fragment reads (point q+2 of this chunk, or point q-14 of the NEXT chunk on steps
-// 14, 15), then 2 patch reads while q < 8.
-constexpr int lds_nr(int q) { return q < 8 ? 2 : 0; }
+// filter-fragment reads (step q+2 of this chunk, or step q-14 of the NEXT chunk on steps
+// 14, 15), then 2 patch reads while q < 6 (a wave reads 12 of its tiles' 16 patch pixels).
+constexpr int lds_nr(int q) { return q < 6 ? 2 : 0; }
 constexpr int lds_n(int q) { return 2 + lds_nr(q); }
 // How many LDS requests are younger than the last one step e's consumers need: the filter
 // fragments of point e (requested two steps earlier; for e < 2 before the barrier, which
@@ -93,6 +93,13 @@ constexpr int lds_wait_count(int e) {
     for (int q = e - PF + 1; q <= e; q++) after += lds_n(q);
   }
   return after > 15 ? 15 : after;
+}
+
+// 8-byte LDS read at an absolute LDS byte address held in a register.  (`smem + offset` leaves a
+// `v_add_u32 v, 0, v` per read in the loop -- the dynamic-LDS base is a symbol the optimizer does not
+// fold -- so the fragment address registers carry the base themselves and are used as pointers.)
+__device__ __forceinline__ f32x2 lds_read2(int addr) {
+  return *(const __attribute__((address_space(3))) f32x2*)(unsigned)addr;
 }
 
 struct TileCoord {
@@ -211,8 +218,15 @@ wino_f2_fused_kernel(const FusedParams prm) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Point split: wave (wt, ph) owns 16 tiles x ALL 64 out-channels x 8 of the 16 Winograd points -- rows
+  // i = 2 ph, 2 ph + 1 of the 4 x 4 point grid.  The two waves of a tile block then share no B^T d B
+  // work (with 16 points per wave both computed the same V): a wave needs 3 of the 4 patch rows (12
+  // reads) and 16 packed adds per iteration instead of 16 reads and 32 adds.  Timing-only ablation of
+  // exactly that (half the adds, 12 reads): 124.3 -> 116.7 us at 256 channels, 41.9 -> 39.3 at 128.
+  // The price is an exchange of partial A^T m A sums between the pair in the epilogue, after which
+  // wave (wt, ph) owns out-channels [32 ph, 32 ph + 32) of its 16 tiles exactly as wave (wt, wk) did.
   const int wt = w >> 1;  // which 16-tile block of the 64
-  const int wk = w & 1;   // which 32-channel half of the 64
+  const int ph = w & 1;   // which half of the point rows; after the epilogue exchange: which 32-channel half
 
   const unsigned u_off = lane * 16;
   const unsigned u_chunk_stride = (unsigned)(KBLK * U_CHUNK_FLOATS * sizeof(float));
@@ -223,25 +237,40 @@ wino_f2_fused_kernel(const FusedParams prm) {
   // ---- fragment read addresses (launch invariant) -------------------------------
   const int t16 = lane & 15, h = lane >> 4;
   // A: tile row tl = wt*16 + t16; 8-byte quarter h holds channels 2h, 2h+1 of the chunk
-  const int a_base = (wt * 16 + t16) * 512 + ((h ^ (((t16 >> 3) & 1) << 1)) << 3);
+  const int lds0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // absolute LDS address of smem[0]
+  const int a_base = lds0 + (wt * 16 + t16) * 512 + ((h ^ (((t16 >> 3) & 1) << 1)) << 3);
   const int a_sw = t16 & 7;
   // Fragment reads must stay plain ds_read_b64: that form banks on 64 dwords, for which the
   // XOR layouts are conflict-free.  hipcc would fuse two reads off one base register into
   // ds_read2_b64 / ds_read2st64_b64, which bank on 32 dwords (2-way conflicts here, half the
   // bytes per clock).  Hiding how the bases relate (empty asm) prevents the fusion; pixels px
   // and px+8 share a base register but are never read in the same pinned step.
-  int a_lo[8];
+  // The three patch rows R0, R1, R2 this wave reads are (d0, d2, d1) for ph = 0 and (d2, d1, d3) for
+  // ph = 1: then B^T d, rows 2 ph and 2 ph + 1, is  R0 - R1  and  R1 + s2 * R2  with s2 = +1 / -1 for
+  // both halves (one code path).  One address register per pixel (12; the raw stage is selected by
+  // bit 15 of each, flipped after every iteration).
+  int a_adr[3][4];
 #pragma unroll
-  for (int p = 0; p < 8; p++) a_lo[p] = a_base + ((p ^ a_sw) << 5);
-#define A_OFF(px) (a_lo[(px) & 7] + (((px) >> 3) << 8))
-  // B: k_local = wk*32 + cb*16 + t16; byte offset inside a filter stage
-  int b_base[2];
+  for (int k = 0; k < 3; k++) {
+    const int row = ph ? (k == 0 ? 2 : k == 1 ? 1 : 3) : (k == 0 ? 0 : k == 1 ? 2 : 1);
 #pragma unroll
-  for (int cb = 0; cb < 2; cb++) {
-    const int kl = wk * 32 + cb * 16 + t16;
-    b_base[cb] = N_RSTAGE * RAW_BYTES + kl * 32 + ((h ^ (((kl >> 3) & 1) << 1)) << 3);
+    for (int j = 0; j < 4; j++) {
+      const int px = 4 * row + j;
+      a_adr[k][j] = a_base + (((px & 7) ^ a_sw) << 5) + ((px >> 3) << 8);
+    }
   }
-  asm volatile("" : "+v"(b_base[1]));
+#define A_OFF(k, j) (a_adr[k][j])
+  // B: logical column block cb' of this wave is out-channel block cb' ^ 2 ph of the item (k_local =
+  // (cb' ^ 2 ph) * 16 + t16): cb' = 0, 1 are the two blocks the wave keeps after the epilogue exchange,
+  // cb' = 2, 3 the two it hands to its partner -- compile-time indices either way.  The byte offset of
+  // the wave's first point (8 ph) inside a filter stage is folded in.
+  int b_base[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; cb++) {
+    const int kl = (cb ^ (2 * ph)) * 16 + t16;
+    b_base[cb] = lds0 + N_RSTAGE * RAW_BYTES + ph * (8 * 2048) + kl * 32 + ((h ^ (((kl >> 3) & 1) << 1)) << 3);
+  }
+  asm volatile("" : "+v"(b_base[1]), "+v"(b_base[2]), "+v"(b_base[3]));
 
   // B^T d B pieces (d, tmp, v are [row i][col j] = index 4i + j; Winograd point e = 4i + j), on
   // channel pairs (v_pk_add_f32)
@@ -266,13 +295,15 @@ wino_f2_fused_kernel(const FusedParams prm) {
   auto add2 = [](const P2& a, const P2& b) { return a + b; };
 #endif
   auto ld2 = [](const char* p) { return *(const f32x2*)p; };
-  auto tmp_col = [&](P2* tmp, const P2* d, int j) {  // B^T d, column j
-    tmp[0 * 4 + j] = sub2(d[0 * 4 + j], d[2 * 4 + j]);
-    tmp[1 * 4 + j] = add2(d[1 * 4 + j], d[2 * 4 + j]);
-    tmp[2 * 4 + j] = sub2(d[2 * 4 + j], d[1 * 4 + j]);
-    tmp[3 * 4 + j] = sub2(d[1 * 4 + j], d[3 * 4 + j]);
+  const float s2f = ph ? -1.f : 1.f;
+  const P2 s2 = {s2f, s2f};
+  // d[k*4 + j] = patch row R_k, column j;  tmp[i'*4 + j] = (B^T d) row 2 ph + i', column j;
+  // v[p], p = 4 i' + j = the wave's point p (Winograd point e = 8 ph + p)
+  auto tmp_col = [&](P2* tmp, const P2* d, int j) {  // B^T d, column j, the wave's two rows
+    tmp[0 * 4 + j] = sub2(d[0 * 4 + j], d[1 * 4 + j]);
+    tmp[1 * 4 + j] = d[1 * 4 + j] + s2 * d[2 * 4 + j];
   };
-  auto v_point = [&](P2* v, const P2* tmp, int e) {  // (B^T d) B, point e
+  auto v_point = [&](P2* v, const P2* tmp, int e) {  // (B^T d) B, point e (0..7)
     const int i = e >> 2, j = e & 3;
     if (j == 0) v[e] = sub2(tmp[i * 4 + 0], tmp[i * 4 + 2]);
     if (j == 1) v[e] = add2(tmp[i * 4 + 1], tmp[i * 4 + 2]);
@@ -395,14 +426,14 @@ wino_f2_fused_kernel(const FusedParams prm) {
   int seg_c0 = c_chunk;            // first chunk of the current segment
   int pend_item = -1;              // a head segment whose ticket is still to be drawn
 
-  f32x4 acc[16][2];
+  f32x4 acc[8][4];   // [the wave's point p][logical column block cb']
 #pragma unroll
-  for (int e = 0; e < 16; e++) {
-    acc[e][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[e][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  P2 v[16];          // V_it at the top of iteration `it`; rewritten in place with V_{it+1}
-  f32x2 bfn[PF][2];  // filter fragments of points 0..PF-1 of the next iteration (requested pre-barrier)
+  for (int e = 0; e < 8; e++)
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) acc[e][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  P2 v[8];           // V_it (the wave's 8 points) at the top of iteration `it`; rewritten in place with V_{it+1}
+  // A pinned step s = 0..15 of an iteration is (point p = s >> 1, column-block pair s & 1): 4 MFMAs.
+  f32x2 bfn[PF][2];  // filter fragments of steps 0..PF-1 of the next iteration (requested pre-barrier)
 
   // ---- prologue: iterations 0 and 1 in flight; V_0 and the first fragments un-pipelined -----
   d_chunk = c_chunk;
@@ -428,22 +459,26 @@ wino_f2_fused_kernel(const FusedParams prm) {
     if (L > 2) dma_advance();
   }
   {
-    P2 d[16];
+    P2 d[12];
 #pragma unroll
-    for (int px = 0; px < 16; px++) d[px] = ld2(smem + A_OFF(px));
-    P2 tmp[16];
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) d[k * 4 + j] = lds_read2(A_OFF(k, j));
+    P2 tmp[8];
 #pragma unroll
     for (int j = 0; j < 4; j++) tmp_col(tmp, d, j);
 #pragma unroll
-    for (int e = 0; e < 16; e++) v_point(v, tmp, e);
+    for (int e = 0; e < 8; e++) v_point(v, tmp, e);
 #pragma unroll
-    for (int e = 0; e < PF; e++) {
-      bfn[e][0] = *(const f32x2*)(smem + b_base[0] + e * 2048);
-      bfn[e][1] = *(const f32x2*)(smem + b_base[1] + e * 2048);
+    for (int e = 0; e < PF; e++) {   // steps 0, 1: point 0, column-block pairs 0 and 1
+      bfn[e][0] = lds_read2(b_base[2 * (e & 1) + 0] + (e >> 1) * 2048);
+      bfn[e][1] = lds_read2(b_base[2 * (e & 1) + 1] + (e >> 1) * 2048);
     }
   }
 #pragma unroll
-  for (int p = 0; p < 8; p++) a_lo[p] ^= RAW_BYTES;   // iteration 0 reads raw_1 from R1
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) a_adr[k][j] ^= RAW_BYTES;   // iteration 0 reads raw_1 from R1
   if (ABLATE & 16) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime)
     // The start stamps go to memory at once: kept in SGPRs across the main loop (which has none to
     // spare) they pushed loop-carried scalars into VGPRs and the build ran 15 % slower than the
@@ -455,11 +490,17 @@ wino_f2_fused_kernel(const FusedParams prm) {
   }
 
   // One pipeline step = iteration `it`.  ONE instantiation: the raw stage that holds raw_{it+1}
-  // is selected by bit 15 of the eight patch base registers a_lo[] (R0 at 0, R1 at 32768; they
+  // is selected by bit 15 of the twelve patch address registers a_adr[][] (R0 at 0, R1 at 32768; they
   // are flipped after every iteration), the filter stage (it % 3) is a run-time offset added to
   // the two fragment base registers, the DMA destinations are scalar.
   // The schedule inside is pinned with sched_barrier(0): left alone, hipcc sinks every
   // ds_read to just before its first use and the wave eats one LDS latency per point.
+  int ub_cur[4], ub_nxt[4];   // b_base[] + the byte offset of filter stage it % 3 / (it + 1) % 3
+#pragma unroll
+  for (int cb = 0; cb < 4; cb++) {
+    ub_cur[cb] = b_base[cb];
+    ub_nxt[cb] = b_base[cb] + U_BYTES;
+  }
   auto body = [&](int it, int rs_dma, int us_cur, int us_nxt, int us_dma) {
     if (ABLATE & 2048) { const unsigned long long t = stamp(); if (it) st_comp += t - st_prev; st_prev = t; }
     if (!(ABLATE & 8)) {
@@ -478,59 +519,70 @@ wino_f2_fused_kernel(const FusedParams prm) {
     // fetch, the walker stands on the range's last chunk (valid addresses) and the pieces land in
     // R[it&1] / U[(it+2)%3] like any others: free stages, disjoint from the ones an epilogue
     // stages its stores in, and drained by the next iteration's vmcnt(0) or by the one before exit.
-    const char* rst = smem;   // raw_{it+1}: the stage is in a_lo[]
-    const char* ucur0 = smem + b_base[0] + us_cur * U_BYTES;   // U_it
-    const char* ucur1 = smem + b_base[1] + us_cur * U_BYTES;
-    const char* unxt0 = smem + b_base[0] + us_nxt * U_BYTES;   // U_{it+1}
-    const char* unxt1 = smem + b_base[1] + us_nxt * U_BYTES;
+    // raw_{it+1}: the stage is in a_adr[][]
+    // fragment base addresses of U_it and U_{it+1}: ub_cur[] / ub_nxt[], loop-carried registers that are
+    // rotated in the iteration's tail (where the wave would wait at the barrier anyway) -- formed here, at
+    // the top, their eight adds sit in front of the iteration's first MFMAs; left inside the reads,
+    // hipcc re-adds the stage offset before every one.  (us_cur / us_nxt: kept for the interface.)
+    (void)us_cur; (void)us_nxt;
+    const int (&ucur)[4] = ub_cur;
+    const int (&unxt)[4] = ub_nxt;
+    // filter fragment of step s (point s >> 1, column blocks 2 (s & 1) + c)
+    auto bread = [&](const int (&base)[4], int s2_, int c) {
+      return lds_read2(base[2 * (s2_ & 1) + c] + (s2_ >> 1) * 2048);
+    };
 
     f32x2 bf[16][2];
 #pragma unroll
     for (int e = 0; e < PF; e++) { bf[e][0] = bfn[e][0]; bf[e][1] = bfn[e][1]; }
-    P2 d[16], tmp[16];
+    P2 d[12], tmp[8];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 16; e++) {
+      const int pt = e >> 1, cbp = e & 1;
       // -- top of the step: every LDS request of this step, before any MFMA.  Consumers sit
       //    at least one step later, so their waits are counted (lgkmcnt(N)), not drains.
       if (ABLATE & 64) {
-        const f32x2 fake = {v[(e + 3) & 15].x, v[(e + 5) & 15].y};
+        const f32x2 fake = {v[(e + 3) & 7].x, v[(e + 5) & 7].y};
         if (e + PF < 16) { bf[e + PF][0] = fake; bf[e + PF][1] = fake; }
         else { bfn[e + PF - 16][0] = fake; bfn[e + PF - 16][1] = fake; }
-      } else if (e + PF < 16) {  // filter fragments of point e+PF
-        bf[e + PF][0] = *(const f32x2*)(ucur0 + (e + PF) * 2048);
-        bf[e + PF][1] = *(const f32x2*)(ucur1 + (e + PF) * 2048);
-      } else {                   // ... and of points 0, 1 of the next iteration
-        bfn[e + PF - 16][0] = *(const f32x2*)(unxt0 + (e + PF - 16) * 2048);
-        bfn[e + PF - 16][1] = *(const f32x2*)(unxt1 + (e + PF - 16) * 2048);
+      } else if (e + PF < 16) {  // filter fragments of step e+PF
+        bf[e + PF][0] = bread(ucur, e + PF, 0);
+        bf[e + PF][1] = bread(ucur, e + PF, 1);
+      } else {                   // ... and of steps 0, 1 of the next iteration
+        bfn[e + PF - 16][0] = bread(unxt, e + PF - 16, 0);
+        bfn[e + PF - 16][1] = bread(unxt, e + PF - 16, 1);
       }
       if (e >= DMA0 && e < DMA0 + 4) {
         issue_raw1(rs_dma, e - DMA0);
       } else if (e >= DMA0 + 4 && e < DMA0 + 8) {
         issue_u1(us_dma, e - DMA0 - 4);
       }
-      // next iteration's A operand rides along: steps 0-7 read its patch (two pixels of patch
-      // column e>>1 per step); B^T d B itself is written below, after the step's MFMAs, and is
-      // deliberately NOT pinned to its step: the optimizer sinks it behind the last MFMA of the
-      // iteration, where it runs as one burst of packed adds while the SIMD's other wave still
-      // has MFMAs to issue.  Measured alternatives, all slower: pinned to steps 2-15 (scalar or
-      // packed, +3..+8 %: arithmetic between a wave's MFMAs delays its own next MFMA, and when it
-      // waits on a patch read the whole wave stalls behind it, in-order issue); B^T d as the
-      // loop-carried state with every point formed one step ahead of its use (+8 %); the two waves
-      // of a SIMD phase-shifted, waves 4-7 transforming at the top of the next iteration instead
-      // (+6 %: the older wave then runs even further ahead and waits longer at the barrier).
+      // next iteration's A operand rides along: steps 0-5 read its 12 patch pixels (two per step, in
+      // the order R0[j], R1[j], R2[j] column by column); B^T d B itself is written below, after the
+      // step's MFMAs, and is deliberately NOT pinned to its step: the optimizer sinks it behind the
+      // last MFMA of the iteration, where it runs as one burst of packed adds while the SIMD's other
+      // wave still has MFMAs to issue.  Measured alternatives (with 16 points per wave), all slower:
+      // pinned to steps 2-15 (scalar or packed, +3..+8 %: arithmetic between a wave's MFMAs delays its
+      // own next MFMA, and when it waits on a patch read the whole wave stalls behind it, in-order
+      // issue); B^T d as the loop-carried state with every point formed one step ahead of its use
+      // (+8 %); the two waves of a SIMD phase-shifted (+6 %).
       // (After the last iteration this works on stale LDS; the result is never used -- cheaper
       // than a branch.)
-      if (e < 8 && !(ABLATE & 32)) {
-        const int j = e >> 1, i0 = (e & 1) * 2;
-        d[(i0 + 0) * 4 + j] = ld2(rst + A_OFF((i0 + 0) * 4 + j));
-        d[(i0 + 1) * 4 + j] = ld2(rst + A_OFF((i0 + 1) * 4 + j));
+      if (e < 6 && !(ABLATE & 32)) {
+        const int q0 = 2 * e, q1 = 2 * e + 1;   // read index q -> (row k = q % 3, column j = q / 3)
+        d[(q0 % 3) * 4 + q0 / 3] = lds_read2(A_OFF(q0 % 3, q0 / 3));
+        d[(q1 % 3) * 4 + q1 / 3] = lds_read2(A_OFF(q1 % 3, q1 / 3));
       }
       __builtin_amdgcn_sched_barrier(0);
       if (!(ABLATE & 96)) wait_lds(lds_wait_count(e));
       __builtin_amdgcn_sched_barrier(0);
-      if (e >= 2 && e <= 8 && (e & 1) == 0 && !(ABLATE & 32)) tmp_col(tmp, d, (e >> 1) - 1);
-      const P2 a = v[e];
+      if (e >= 3 && e <= 7 && e != 5 && !(ABLATE & 32) && !(ABLATE & 8192)) tmp_col(tmp, d, e == 3 ? 0 : e == 4 ? 1 : e == 6 ? 2 : 3);
+      if ((ABLATE & 8192) && e == 7) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) asm volatile("" :: "v"(d[i]));
+      }
+      const P2 a = v[pt];
       const f32x2 b0 = bf[e][0], b1 = bf[e][1];
       if (ABLATE & 4) {  // keep the operands live, skip the matrix pipe
         asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y));
@@ -541,21 +593,21 @@ wino_f2_fused_kernel(const FusedParams prm) {
         // (dst != SrcC), which costs the dependent MFMA several passes.  The compiler does not
         // see MFMA hazards of inline asm: the only VALU access to acc[] is in the epilogue, behind
         // explicit s_nops.
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][0]) : "v"(a.x), "v"(b0.x));
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][1]) : "v"(a.x), "v"(b1.x));
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][0]) : "v"(a.y), "v"(b0.y));
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[e][1]) : "v"(a.y), "v"(b1.y));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[pt][2 * cbp + 0]) : "v"(a.x), "v"(b0.x));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[pt][2 * cbp + 1]) : "v"(a.x), "v"(b1.x));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[pt][2 * cbp + 0]) : "v"(a.y), "v"(b0.y));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[pt][2 * cbp + 1]) : "v"(a.y), "v"(b1.y));
       }
-      if (!(ABLATE & 32)) {
-        if (e >= 9 && e < 15) {  // points 2(e-9), 2(e-9)+1 < e have retired
-          v_point(v, tmp, 2 * (e - 9));
-          v_point(v, tmp, 2 * (e - 9) + 1);
-        }
+      if ((ABLATE & 4096) && !(ABLATE & 8192) && e == 9) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("" :: "v"(tmp[i]));
+      }
+      if (!(ABLATE & 32) && !(ABLATE & (4096 | 8192))) {
+        // point p retires with step 2 p + 1; all patch reads are in by step 7
+        if (e >= 9 && e < 15) v_point(v, tmp, e - 9);   // points 0..5
         if (e == 15) {
-          v_point(v, tmp, 12);
-          v_point(v, tmp, 13);
-          v_point(v, tmp, 14);
-          v_point(v, tmp, 15);
+          v_point(v, tmp, 6);
+          v_point(v, tmp, 7);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -629,32 +681,66 @@ wino_f2_fused_kernel(const FusedParams prm) {
     load_bn(c_item, bn_sc, bn_bi);
     unsigned pend_old = 0;
     if (pend_item >= 0) pend_old = draw_ticket(pend_item);   // in flight while A^T m A runs
-    // A^T m A (C/D layout: col = lane&15, row = 4*(lane>>4)+r):
-    // y[r][cb] = the 2x2 output pixels (p = 2a+b) of tile row 4h+r, out-channel cb*16+t16.
-    f32x4 y[4][2];
+    // A^T m A (C/D layout: col = lane&15, row = 4*(lane>>4)+r).  The wave holds point rows i = 2 ph and
+    // 2 ph + 1 (local rows 0, 1) for all four column blocks.  Per (tile row r, column block cb):
+    //   column transform inside each point row:  c0(i) = m_i0 + m_i1 + m_i2,  c1(i) = m_i1 - m_i2 - m_i3
+    //   row transform:  Y[0][b] = c_b(0) + c_b(1) + c_b(2),  Y[1][b] = c_b(1) - c_b(2) - c_b(3)
+    // of which this wave can form the part of its two rows:
+    //   ph = 0:  P[0][b] = c_b(0) + c_b(1),  P[1][b] = c_b(1)      ph = 1:  P[0][b] = c_b(2),  P[1][b] = -(c_b(2) + c_b(3))
+    // (selects on the wave-uniform ph, no multiplies by 0 / +-1: exact, and an Inf in one part cannot
+    // turn the other into NaN).  Pixel index p = 2a + b.
+    // The parts of logical column blocks 2, 3 go to the partner wave (w ^ 1, the same tiles) through
+    // this wave's 8 KB of the free LDS stages; the partner's parts of MY blocks 0, 1 come back the same
+    // way.  y[r][cb] = the 2x2 output pixels of tile row 4h+r, out-channel (32 ph) + cb*16 + t16 --
+    // from here on exactly what the wave held when it owned 16 points of 32 out-channels.
+    const bool ph1 = (wv & 1) != 0;
+    auto part = [&](int r, int cb) {
+      float c[2][2];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-#pragma unroll
-      for (int cb = 0; cb < 2; cb++) {
-        float t0[4], t1[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float m0 = acc[0 * 4 + j][cb][r], m1 = acc[1 * 4 + j][cb][r];
-          const float m2 = acc[2 * 4 + j][cb][r], m3 = acc[3 * 4 + j][cb][r];
-          t0[j] = m0 + m1 + m2;
-          t1[j] = m1 - m2 - m3;
-        }
-        y[r][cb][0] = t0[0] + t0[1] + t0[2];
-        y[r][cb][1] = t0[1] - t0[2] - t0[3];
-        y[r][cb][2] = t1[0] + t1[1] + t1[2];
-        y[r][cb][3] = t1[1] - t1[2] - t1[3];
+      for (int i = 0; i < 2; i++) {
+        const float m0 = acc[i * 4 + 0][cb][r], m1 = acc[i * 4 + 1][cb][r];
+        const float m2 = acc[i * 4 + 2][cb][r], m3 = acc[i * 4 + 3][cb][r];
+        c[i][0] = m0 + m1 + m2;
+        c[i][1] = m1 - m2 - m3;
       }
+      f32x4 o;
+#pragma unroll
+      for (int bb = 0; bb < 2; bb++) {
+        const float sum = c[0][bb] + c[1][bb];
+        o[bb] = ph1 ? c[0][bb] : sum;          // a = 0
+        o[2 + bb] = ph1 ? -sum : c[1][bb];     // a = 1
+      }
+      return o;
+    };
+    f32x4 y[4][2];
+    {
+      char* const xmine = wreg + ln * 16;
+      const char* const xpart = smem + ((wv ^ 1) < 4 ? rfree + (wv ^ 1) * 8192 : ufree + ((wv ^ 1) - 4) * 8192) + ln * 16;
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) *(f32x4*)(xmine + (2 * r + cb) * 1024) = part(r, 2 + cb);
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) y[r][cb] = part(r, cb);
+      // every wave's outgoing parts are in LDS (its own ds_writes drained) before anyone reads them
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) y[r][cb] += *(const f32x4*)(xpart + (2 * r + cb) * 1024);
+      // ... and read, before the finalize below stages output rows through the same LDS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-      acc[e][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[e][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int e = 0; e < 8; e++)
+#pragma unroll
+      for (int cb = 0; cb < 4; cb++) acc[e][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     phase(1);
     const bool whole = seg_c0 == 0 && c_chunk == nchunks - 1;
     // up to two items to look at: [0] this segment's, [1] the deferred head segment's
@@ -791,11 +877,21 @@ wino_f2_fused_kernel(const FusedParams prm) {
       for (int k = 0; k < n; k++) {
         body(it, it & 1, us, next(us), next(next(us)));
 #pragma unroll
-        for (int p = 0; p < 8; p++) a_lo[p] ^= RAW_BYTES;
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) a_adr[k][j] ^= RAW_BYTES;
         if (it + 3 < L) dma_advance();
         us_last = us;
         us = next(us);
         it++;
+        {   // rotate the filter-fragment bases: U_{it} was U_{it+1}; the new U_{it+1} is stage next(us)
+          const int off = next(us) * U_BYTES;
+#pragma unroll
+          for (int cb = 0; cb < 4; cb++) {
+            ub_cur[cb] = ub_nxt[cb];
+            ub_nxt[cb] = b_base[cb] + off;
+          }
+        }
       }
       // the segment's last iteration was it-1: raw stage R[it & 1] and filter stage U[us_last] are free
       const bool last_of_range = it == L;

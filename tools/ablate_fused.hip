@@ -78,6 +78,13 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 3 && argv[3][0] == 'h') {   // timing only: what the parts of the A path cost
+    run<0>(in, U, b, s, out, 128, C, K, 3000);
+    for (int i = 0; i < 3; i++)
+      printf("full %.1f   no v_point %.1f   no tmp_col + v_point (reads only) %.1f   no A path %.1f us\n", run<0>(in, U, b, s, out, 128, C, K, 200),
+             run<4096>(in, U, b, s, out, 128, C, K, 200), run<8192>(in, U, b, s, out, 128, C, K, 200), run<32>(in, U, b, s, out, 128, C, K, 200));
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 'q') {  // quick mode: just the product kernel at N = 128, three trials of 50 launches
     run<0>(in, U, b, s, out, 128, C, K, 3000);   // clock ramp: ~0.4 s of the same kernel (see bench.py, preheat)
     float t[3];
