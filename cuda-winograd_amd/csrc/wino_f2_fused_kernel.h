@@ -49,6 +49,9 @@ constexpr int LDS_BYTES = N_RSTAGE * RAW_BYTES + N_USTAGE * U_BYTES;  // 163840 
 constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
 constexpr int PF = 2;                        // filter-fragment prefetch distance (points); 2..6 measured equal
 constexpr int SLAB_BYTES = TB * 4 * KB * 4;  // 65536: pre-BN output of one item (64 tiles x 2x2 px x 64 k)
+#ifndef WINO_UNROLL2
+#define WINO_UNROLL2 1   // two copies of the loop body, one per raw-stage parity: the stage is an immediate of the patch reads
+#endif
 #ifndef WINO_SCALAR_BTDB
 #define WINO_SCALAR_BTDB 0
 #endif
@@ -101,7 +104,6 @@ constexpr int lds_wait_count(int e) {
 __device__ __forceinline__ f32x2 lds_read2(int addr) {
   return *(const __attribute__((address_space(3))) f32x2*)(unsigned)addr;
 }
-
 struct TileCoord {
   int n, ty, tx;
 };
@@ -475,10 +477,12 @@ wino_f2_fused_kernel(const FusedParams prm) {
       bfn[e][1] = lds_read2(b_base[2 * (e & 1) + 1] + (e >> 1) * 2048);
     }
   }
+#if !WINO_UNROLL2
 #pragma unroll
   for (int k = 0; k < 3; k++)
 #pragma unroll
     for (int j = 0; j < 4; j++) a_adr[k][j] ^= RAW_BYTES;   // iteration 0 reads raw_1 from R1
+#endif
   if (ABLATE & 16) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime)
     // The start stamps go to memory at once: kept in SGPRs across the main loop (which has none to
     // spare) they pushed loop-carried scalars into VGPRs and the build ran 15 % slower than the
@@ -501,7 +505,11 @@ wino_f2_fused_kernel(const FusedParams prm) {
     ub_cur[cb] = b_base[cb];
     ub_nxt[cb] = b_base[cb] + U_BYTES;
   }
-  auto body = [&](int it, int rs_dma, int us_cur, int us_nxt, int us_dma) {
+  // (WINO_UNROLL2: the body exists twice, once per parity of `it`; iteration `it` reads raw_{it+1} from
+  //  R[(it + 1) & 1], which is then a compile-time offset of the patch reads -- a_adr[][] stay on R0 and the
+  //  twelve v_xor toggles per iteration go away.)
+  auto body = [&](auto par_c, int it, int rs_dma, int us_cur, int us_nxt, int us_dma) {
+    constexpr int ROFF = WINO_UNROLL2 ? (decltype(par_c)::value ? 0 : RAW_BYTES) : 0;
     if (ABLATE & 2048) { const unsigned long long t = stamp(); if (it) st_comp += t - st_prev; st_prev = t; }
     if (!(ABLATE & 8)) {
       wait_vmem_all();   // my DMA pieces of raw_{it+1} and U_{it+1} have landed
@@ -525,8 +533,10 @@ wino_f2_fused_kernel(const FusedParams prm) {
     // the top, their eight adds sit in front of the iteration's first MFMAs; left inside the reads,
     // hipcc re-adds the stage offset before every one.  (us_cur / us_nxt: kept for the interface.)
     (void)us_cur; (void)us_nxt;
-    const int (&ucur)[4] = ub_cur;
-    const int (&unxt)[4] = ub_nxt;
+    // (WINO_UNROLL2: the two copies of the body use the two register sets in swapped roles, so the rotation
+    //  is four adds into the set that has just gone dead instead of four moves and four adds)
+    const int (&ucur)[4] = (WINO_UNROLL2 && decltype(par_c)::value) ? ub_nxt : ub_cur;
+    const int (&unxt)[4] = (WINO_UNROLL2 && decltype(par_c)::value) ? ub_cur : ub_nxt;
     // filter fragment of step s (point s >> 1, column blocks 2 (s & 1) + c)
     auto bread = [&](const int (&base)[4], int s2_, int c) {
       return lds_read2(base[2 * (s2_ & 1) + c] + (s2_ >> 1) * 2048);
@@ -571,8 +581,8 @@ wino_f2_fused_kernel(const FusedParams prm) {
       // than a branch.)
       if (e < 6 && !(ABLATE & 32)) {
         const int q0 = 2 * e, q1 = 2 * e + 1;   // read index q -> (row k = q % 3, column j = q / 3)
-        d[(q0 % 3) * 4 + q0 / 3] = lds_read2(A_OFF(q0 % 3, q0 / 3));
-        d[(q1 % 3) * 4 + q1 / 3] = lds_read2(A_OFF(q1 % 3, q1 / 3));
+        d[(q0 % 3) * 4 + q0 / 3] = lds_read2(A_OFF(q0 % 3, q0 / 3) + ROFF);
+        d[(q1 % 3) * 4 + q1 / 3] = lds_read2(A_OFF(q1 % 3, q1 / 3) + ROFF);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (!(ABLATE & 96)) wait_lds(lds_wait_count(e));
@@ -873,13 +883,13 @@ wino_f2_fused_kernel(const FusedParams prm) {
       const int n = c_tail > 0 && c_tail < nchunks - c_chunk ? c_tail : nchunks - c_chunk;
       c_chunk += n - 1;   // its last chunk
       int us_last = us;
-#pragma unroll 1
-      for (int k = 0; k < n; k++) {
-        body(it, it & 1, us, next(us), next(next(us)));
+      auto tail = [&](auto par_c) {   // everything between two bodies
+#if !WINO_UNROLL2
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
           for (int j = 0; j < 4; j++) a_adr[k][j] ^= RAW_BYTES;
+#endif
         if (it + 3 < L) dma_advance();
         us_last = us;
         us = next(us);
@@ -888,11 +898,39 @@ wino_f2_fused_kernel(const FusedParams prm) {
           const int off = next(us) * U_BYTES;
 #pragma unroll
           for (int cb = 0; cb < 4; cb++) {
+#if WINO_UNROLL2
+            // the set the body just used as "current" is dead: it becomes the next body's "next"
+            if (decltype(par_c)::value) ub_nxt[cb] = b_base[cb] + off;
+            else ub_cur[cb] = b_base[cb] + off;
+#else
             ub_cur[cb] = ub_nxt[cb];
             ub_nxt[cb] = b_base[cb] + off;
+#endif
           }
         }
+      };
+#if WINO_UNROLL2
+      {
+        int k = 0;
+#pragma unroll 1
+        for (;;) {
+          if (!(it & 1)) {
+            body(std::integral_constant<int, 0>{}, it, 0, us, next(us), next(next(us)));
+            tail(std::integral_constant<int, 0>{});
+            if (++k == n) break;
+          }
+          body(std::integral_constant<int, 1>{}, it, 1, us, next(us), next(next(us)));
+          tail(std::integral_constant<int, 1>{});
+          if (++k == n) break;
+        }
       }
+#else
+#pragma unroll 1
+      for (int k = 0; k < n; k++) {
+        body(std::integral_constant<int, 0>{}, it, it & 1, us, next(us), next(next(us)));
+        tail(std::integral_constant<int, 0>{});
+      }
+#endif
       // the segment's last iteration was it-1: raw stage R[it & 1] and filter stage U[us_last] are free
       const bool last_of_range = it == L;
       if (ABLATE & 2048) { const unsigned long long t = stamp(); st_comp += t - st_prev; st_prev = t; }
