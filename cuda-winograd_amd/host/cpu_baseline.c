@@ -122,9 +122,10 @@ int wino_cpu_conv(int kind, const float* in, const float* w, const float* bias, 
   atomic_init(&wk.next_block, 0);
   if (threads < 1) threads = 1;
   if (threads > 1024) threads = 1024;
-  {   /* blocks of up to 28 output pixels, at least ~4 per thread; never more threads than blocks */
+  {   /* blocks of 7..28 output pixels, about 4 per thread when the layer is large enough; never more
+       * threads than blocks (N = 1: 28 threads of 7 pixels -- a thread per pixel costs more to start than to run) */
     long rpb = wk.rows / (4L * threads);
-    wk.rows_per_block = rpb < 1 ? 1 : rpb > MAX_ROWS_PER_BLOCK ? MAX_ROWS_PER_BLOCK : (int)rpb;
+    wk.rows_per_block = rpb < 7 ? 7 : rpb > MAX_ROWS_PER_BLOCK ? MAX_ROWS_PER_BLOCK : (int)rpb;
     const long nblocks = (wk.rows + wk.rows_per_block - 1) / wk.rows_per_block;
     if (threads > nblocks) threads = (int)nblocks;
   }
