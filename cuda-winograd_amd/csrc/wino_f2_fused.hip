@@ -10,20 +10,22 @@
 //                chunks of BC=8 channels ("chunk iterations").  The launch is balanced by
 //                iterations: whole-item rounds + a stream-K tail (wino_f2_fused_kernel.h).
 //   workgroup  = 512 threads = 8 waves (2 per SIMD), all 160 KB of the CU's LDS.
-//   wave (wt,wk) = 16 tiles x 32 out-channels x 16 points
-//                = 32 accumulator tiles of v_mfma_f32_16x16x4_f32 (128 acc VGPRs).
+//   wave (wt,ph) = 16 tiles x all 64 out-channels x 8 of the 16 points (rows 2 ph, 2 ph + 1 of the point grid)
+//                = 32 accumulator tiles of v_mfma_f32_16x16x4_f32 (128 acc VGPRs); no two waves repeat a
+//                  transform (round 1: 16 tiles x 32 out-channels x 16 points, B^T d B twice per tile block).
 //   per chunk  : LDS-DMA (buffer_load_dwordx4 ... lds) stages
 //                  raw[64 tiles][16 px][8 c]   (the 4x4 input patches, 32 KB, 2 stages)
 //                  U  [16 pts][64 k][8 c]      (pre-packed filter chunk, 32 KB, 3 stages)
 //                two iterations ahead of the MFMAs, continuously across items.
-//   A operand  : each lane reads its tile's 4x4 patch for 2 channels (16 x ds_read_b64),
-//                applies B^T d B in registers (32 packed adds) -> V[16 pts];
-//                no cross-lane traffic is needed because the MFMA A-fragment wants
+//   A operand  : each lane reads 3 of its tile's 4 patch rows for 2 channels (12 x ds_read_b64, addresses held
+//                as absolute LDS pointers in registers) and applies its half of B^T d B in registers (16 packed
+//                operations) -> V[8 pts]; no cross-lane traffic is needed because the MFMA A-fragment wants
 //                exactly "one tile row, one channel" per lane.
 //   B operand  : ds_read_b64 of the packed filter chunk.
-//   epilogue   : the 16 accumulators of one (tile, k) sit in the SAME lane/register slot
-//                of 16 different MFMA tiles, so A^T m A is 24 in-lane adds; then
-//                scale*y+bias, ReLU; each wave's tiles go through its own 8 KB of LDS and leave as
+//   loop       : two copies of the body, one per raw-stage parity (the stage is an immediate of the patch reads).
+//   epilogue   : the wave's partial A^T m A (its two point rows) in-lane; the halves of a (tile, out-channel)
+//                meet through LDS (wave pair w, w ^ 1), after which wave (wt, ph) owns 16 tiles x 32
+//                out-channels: scale*y+bias, ReLU; the tiles go through the wave's own 8 KB of LDS and leave as
 //                whole 128-byte runs of the padded NHWC output; the zero ring is written once per
 //                launch by a flat ring pass.
 // Small batches (the reference's N = 1) take wino_f2_small_kernel.h instead; feature maps other
