@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "wino_driver_set_gpu_alias", "wino_driver_set_stdout_compat", "wino_driver_get_stdout_compat",
     "wino_driver_cpu_baseline", "wino_last_status_name", "wino_debug_reload_knobs",
     "wino_residual_block_prepare", "wino_residual_block_prepare_hw", "wino_diag_conv3x3_clock",
+    "wino_debug_tickets_in_use",
     # reference entry points + helpers (Kernel*.h, util.h)
     "kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in",
     "kernel_256_1_out", "get_parameter", "transpose", "getTimeMicroseconds64", "output_checker",
@@ -144,6 +145,14 @@ def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
 
 def _stream() -> c_void_p:
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def tickets_in_use() -> int:
+    """Diagnostic (tests): non-zero stream-K ticket counters of the current stream's scratch after a
+    synchronise.  Every launch must leave 0."""
+    n = c_long(0)
+    _check(lib().wino_debug_tickets_in_use(_stream(), ctypes.byref(n)), "wino_debug_tickets_in_use")
+    return int(n.value)
 
 
 def _on_current_device(*tensors) -> None:

@@ -167,8 +167,9 @@ template <int ABLATE, bool GEN = false>
 __global__ void __launch_bounds__(NTHREADS, 2)
 wino_f2_fused_kernel(const FusedParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const float* __restrict__ in = prm.in;
-  const float* __restrict__ Uq = prm.Uq;
+  const float* in = prm.in;
+  const float* Uq = prm.Uq;
+  asm volatile("" : "+s"(in), "+s"(Uq));
   const int N = prm.N, C = prm.C, K = prm.K;
   const unsigned sk_q = prm.sk_q, sk_rem = prm.sk_rem;
   const int ndp = prm.ndp;
@@ -296,7 +297,6 @@ wino_f2_fused_kernel(const FusedParams prm) {
   auto sub2 = [](const P2& a, const P2& b) { return a - b; };
   auto add2 = [](const P2& a, const P2& b) { return a + b; };
 #endif
-  auto ld2 = [](const char* p) { return *(const f32x2*)p; };
   const float s2f = ph ? -1.f : 1.f;
   const P2 s2 = {s2f, s2f};
   // d[k*4 + j] = patch row R_k, column j;  tmp[i'*4 + j] = (B^T d) row 2 ph + i', column j;
@@ -422,11 +422,18 @@ wino_f2_fused_kernel(const FusedParams prm) {
   // ---- the compute stream's position --------------------------------------------
   // (readfirstlane: the divisions run on the vector unit; without it the walkers' scalar state --
   //  and with it the LDS-DMA scalar offsets -- would be treated as divergent)
-  int c_tail = Lt;                 // tail iterations still to compute
-  int c_item = __builtin_amdgcn_readfirstlane(Lt > 0 ? tail_item0 + (int)(t_begin / (unsigned)nchunks) : lg);
+  int c_tail_vg = Lt;              // tail iterations still to compute
+  // (The current item and the kind of the current segment are looked at by the epilogue and the segment switch
+  //  only: they ride through the main loop in VGPRs, like pend_vg below, and are read back with readfirstlane
+  //  where they are needed.  The loop has no SGPR to spare.)
+  int c_item_vg = __builtin_amdgcn_readfirstlane(Lt > 0 ? tail_item0 + (int)(t_begin / (unsigned)nchunks) : lg);
   int c_chunk = __builtin_amdgcn_readfirstlane(Lt > 0 ? (int)(t_begin % (unsigned)nchunks) : 0);
-  int seg_c0 = c_chunk;            // first chunk of the current segment
-  int pend_item = -1;              // a head segment whose ticket is still to be drawn
+  int seg_kind_vg = 0;             // bit 1: the current segment starts its item, bit 0: it is the whole item
+  // a partial segment whose ticket is drawn in the next epilogue (-1: none).  Parked in a VGPR across the
+  // main loop ("+v"; read back with readfirstlane in the epilogue): the loop has no SGPR to spare -- as a
+  // scalar it pushed a buffer descriptor into VGPR lanes, four v_readlane per iteration.
+  int pend_vg = -1;
+  asm volatile("" : "+v"(pend_vg));
 
   f32x4 acc[8][4];   // [the wave's point p][logical column block cb']
 #pragma unroll
@@ -440,7 +447,8 @@ wino_f2_fused_kernel(const FusedParams prm) {
   // ---- prologue: iterations 0 and 1 in flight; V_0 and the first fragments un-pipelined -----
   d_chunk = c_chunk;
   d_tail = Lt;
-  dma_set_item(c_item);
+  dma_set_item(c_item_vg);
+  asm volatile("" : "+v"(c_item_vg));
 #pragma unroll
   for (int j = 0; j < 4; j++) issue_raw1(0, j);
 #pragma unroll
@@ -687,8 +695,11 @@ wino_f2_fused_kernel(const FusedParams prm) {
     };
 
     // folded BN of this segment's item (this lane's two out-channels); in flight during A^T m A
+    const int c_item = __builtin_amdgcn_readfirstlane(c_item_vg), seg_kind = __builtin_amdgcn_readfirstlane(seg_kind_vg);
     float bn_sc[2], bn_bi[2];
     load_bn(c_item, bn_sc, bn_bi);
+    // The previous segment's deferred ticket is drawn now.
+    int pend_item = __builtin_amdgcn_readfirstlane(pend_vg);
     unsigned pend_old = 0;
     if (pend_item >= 0) pend_old = draw_ticket(pend_item);   // in flight while A^T m A runs
     // A^T m A (C/D layout: col = lane&15, row = 4*(lane>>4)+r).  The wave holds point rows i = 2 ph and
@@ -752,16 +763,22 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #pragma unroll
       for (int cb = 0; cb < 4; cb++) acc[e][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     phase(1);
-    const bool whole = seg_c0 == 0 && c_chunk == nchunks - 1;
+    const bool whole = (seg_kind & 1) != 0;
     // up to two items to look at: [0] this segment's, [1] the deferred head segment's
-    int job0 = -1, job1 = -1;
+    // (job1 is taken BEFORE this segment may re-arm pend_item with its own deferred ticket -- the second
+    //  partial segment of a range that goes on to whole items.  Round 1 tested pend_item != c_item after the
+    //  re-arm and lost the drawn item in exactly that case: harmless while the range's neighbour, whose
+    //  ticket on that item waits behind a whole item, draws last; an item never finalized when this
+    //  workgroup starts late -- a grid beyond the CU count, or CUs shared with another stream's kernel.)
+    int job0 = -1, job1 = pend_item;
+    pend_item = -1;
     unsigned old0 = 0;
     if (whole) {
       job0 = c_item;
     } else if (!(ABLATE & 1024)) {
       // slab slot: 2l for the segment that continues an item (head of l's range), 2l+1 for the
       // one that starts an item
-      const unsigned my_slot = 2u * lg + (seg_c0 == 0 ? 1u : 0u);
+      const unsigned my_slot = 2u * lg + ((seg_kind & 2) ? 1u : 0u);
 #pragma unroll
       for (int q = 0; q < 8; q++)
         slab_store16(y[q >> 1][q & 1], rsrc_slab, slab_voff + q * 1024, my_slot * SLAB_BYTES);
@@ -773,10 +790,8 @@ wino_f2_fused_kernel(const FusedParams prm) {
         job0 = c_item;
       }
     }
-    if (pend_item >= 0 && pend_item != c_item) {
-      job1 = pend_item;
-      pend_item = -1;
-    }
+    pend_vg = pend_item;
+    asm volatile("" : "+v"(pend_vg));
     phase(2);
 #pragma unroll 1
     for (int j = 0; j < 2; j++) {
@@ -880,8 +895,16 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #pragma unroll 1
     for (;;) {
       // iterations of this segment: to the end of the item, or of the tail range
+      int c_tail = __builtin_amdgcn_readfirstlane(c_tail_vg);
       const int n = c_tail > 0 && c_tail < nchunks - c_chunk ? c_tail : nchunks - c_chunk;
-      c_chunk += n - 1;   // its last chunk
+      seg_kind_vg = c_chunk == 0 ? (n == nchunks ? 3 : 2) : 0;
+      asm volatile("" : "+v"(seg_kind_vg));
+      // the walker's state after this segment, settled now so that neither n nor c_chunk lives across the loop:
+      // c_tail < 0 = "the tail ends with this segment"
+      if (c_tail > 0 && (c_tail -= n) == 0) c_tail = -1;
+      c_tail_vg = c_tail;
+      asm volatile("" : "+v"(c_tail_vg));
+      c_chunk = 0;   // every later segment starts its item
       int us_last = us;
       auto tail = [&](auto par_c) {   // everything between two bodies
 #if !WINO_UNROLL2
@@ -911,22 +934,22 @@ wino_f2_fused_kernel(const FusedParams prm) {
       };
 #if WINO_UNROLL2
       {
-        int k = 0;
+        int k = n;
 #pragma unroll 1
         for (;;) {
           if (!(it & 1)) {
             body(std::integral_constant<int, 0>{}, it, 0, us, next(us), next(next(us)));
             tail(std::integral_constant<int, 0>{});
-            if (++k == n) break;
+            if (--k == 0) break;
           }
           body(std::integral_constant<int, 1>{}, it, 1, us, next(us), next(next(us)));
           tail(std::integral_constant<int, 1>{});
-          if (++k == n) break;
+          if (--k == 0) break;
         }
       }
 #else
 #pragma unroll 1
-      for (int k = 0; k < n; k++) {
+      for (int k = n; k > 0; k--) {
         body(std::integral_constant<int, 0>{}, it, it & 1, us, next(us), next(next(us)));
         tail(std::integral_constant<int, 0>{});
       }
@@ -937,10 +960,14 @@ wino_f2_fused_kernel(const FusedParams prm) {
       epilogue(last_of_range, (it & 1) * RAW_BYTES, N_RSTAGE * RAW_BYTES + us_last * U_BYTES);
       if (ABLATE & 2048) { const unsigned long long t = stamp(); st_epi += t - st_prev; st_prev = t; }
       if (last_of_range) break;
-      if (c_tail > 0 && (c_tail -= n) == 0) c_item = lg;   // tail done: first whole item
-      else c_item += c_tail > 0 ? 1 : G;
-      c_chunk = 0;
-      seg_c0 = 0;
+      c_tail = __builtin_amdgcn_readfirstlane(c_tail_vg);
+      if (c_tail < 0) {   // tail done: first whole item
+        c_item_vg = lg;
+        c_tail_vg = 0;
+      } else {
+        c_item_vg += c_tail > 0 ? 1 : G;
+      }
+      asm volatile("" : "+v"(c_item_vg), "+v"(c_tail_vg));
     }
   }
 #undef A_OFF

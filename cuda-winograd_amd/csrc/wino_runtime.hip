@@ -162,6 +162,30 @@ int wino_debug_reload_knobs(void) {
   return WINO_OK;
 }
 
+// Invariant check for tests: every stream-K launch returns the ticket counters it used to zero (the
+// last arriver of an item resets them), so between launches all counters of a stream's scratch -- the
+// current generation and the retired ones -- read 0.  Synchronises the stream and counts the non-zero ones
+// of the current generation on the current device.
+int wino_debug_tickets_in_use(wino_stream_t stream, long* nonzero) {
+  if (!nonzero) return WINO_E_ARG;
+  *nonzero = 0;
+  int dev = 0;
+  WINO_HIP(hipGetDevice(&dev));
+  WINO_HIP(hipStreamSynchronize((hipStream_t)stream));
+  unsigned* tickets = nullptr;
+  size_t n = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (auto& e : g_ws)
+      if (e.dev == dev && e.stream == (hipStream_t)stream) { tickets = e.tickets; n = e.n_tickets; }
+  }
+  if (!tickets) return WINO_OK;
+  std::vector<unsigned> host(n);
+  WINO_HIP(hipMemcpy(host.data(), tickets, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+  for (unsigned v : host) *nonzero += v != 0;
+  return WINO_OK;
+}
+
 int wino_device_count(int* count) {
   if (!count) return WINO_E_ARG;
   *count = 0;

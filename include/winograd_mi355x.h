@@ -47,7 +47,7 @@ extern "C" {
  * scratch; wino_conv3x3_bn_relu(_hw) take any batch (they used to reject tensors of 4 GiB);
  * wino_last_status_name, wino_debug_reload_knobs, wino_residual_block_prepare(_hw),
  * wino_driver_set_gpu_alias, wino_driver_set_stdout_compat, wino_driver_cpu_baseline,
- * wino_diag_conv3x3_clock.  The library-owned stream-K scratch is never freed or moved while its
+ * wino_diag_conv3x3_clock, wino_debug_tickets_in_use.  The library-owned stream-K scratch is never freed or moved while its
  * stream lives (it used to be reallocated when a larger shape arrived). */
 #define WINO_ABI_VERSION 1
 
@@ -304,6 +304,10 @@ int wino_driver_cpu_baseline(wino_cpu_baseline_result* r);
 /* ---- diagnostics (measurement infrastructure, not part of the reference interface) -------------
  * Re-reads the WINO_* developer knobs (the library reads them once per process). */
 int wino_debug_reload_knobs(void);
+/* Synchronises `s` and counts the non-zero stream-K ticket counters of its scratch on the current device
+ * (0 when the stream has none).  Every launch leaves them at zero: a non-zero count between launches
+ * means an item was never finalized (tests assert 0). */
+int wino_debug_tickets_in_use(wino_stream_t s, long* nonzero);
 /* The 3x3 throughput kernel's stamped build (same source, s_memtime / s_memrealtime around its main
  * loop): runs one launch of it on `s` with the arguments of wino_conv3x3_bn_relu and writes four
  * uint64 per workgroup to stamps_dev (at least 4 * 2048 uint64): {shader cycles, 100 MHz ticks} at the

@@ -240,6 +240,67 @@ def test_conv3x3_streamk_decompositions_agree(N, C, K, pkg, O, torch_dev, knobs)
         assert (a.cpu().numpy()[:, _ring(), :] == 0).all()
 
 
+@pytest.mark.parametrize("N,C,K,grids", [(128, 256, 256, (257, 300, 333, 391, 400)), (128, 64, 256, (300, 391)),
+                                         (100, 128, 128, (257, 290))])
+def test_conv3x3_late_workgroups_finish_their_items(N, C, K, grids, pkg, torch_dev, knobs):
+    """Whole-item rounds + a stream-K tail on a grid LARGER than the CU count: the workgroups beyond the
+    first wave of residents start when others have finished, so the order in which an item's tickets are
+    drawn is the opposite of the usual one.  A range of such a launch holds up to three segments -- the end
+    of one tail item, the start of the next (both partial, both with deferred tickets), then whole items
+    -- and round 1's kernel dropped the first deferred ticket's result when the second was armed: with the
+    usual order somebody else draws last and nothing shows; with late workgroups the item was never
+    finalized and its counters stayed non-zero, which corrupted every later launch on the stream (found by
+    tools/soak.py with a second stream competing for the CUs).  Here: NaN-filled outputs, every element
+    against the automatic grid's result and (sampled images) the direct comparator, counters back at zero
+    after every launch, and the automatic grid still right afterwards."""
+    torch, dev = torch_dev
+    knobs.set("WINO_3X3_ALGO", "big")
+    g = torch.Generator(device="cpu").manual_seed(N + C)
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
+    x, w, s, b = mk(N, 16, 16, C), mk(K, C, 3, 3), mk(K), mk(K)
+    U = pkg.filter_transform_f2(w)
+    knobs.unset("WINO_SK_GRID")
+    ref = pkg.conv3x3_bn_relu(x, U, b, s).clone()
+    assert pkg.tickets_in_use() == 0
+    direct = pkg.conv3x3_direct(x[:3], w, b, s)
+    scale = float(ref.abs().max())
+    assert float((ref[:3] - direct).abs().max()) < TIGHT * scale
+    for grid in grids:
+        knobs.set("WINO_SK_GRID", str(grid))
+        for rep in range(3):
+            out = torch.full((N, 16, 16, K), float("nan"), device=dev)
+            pkg.conv3x3_bn_relu(x, U, b, s, out=out)
+            assert pkg.tickets_in_use() == 0, f"grid {grid}: an item was left unfinished"
+            assert not bool(torch.isnan(out).any()), f"grid {grid}: outputs never written"
+            assert float((out - ref).abs().max()) < 2e-6 * scale, f"grid {grid}"
+    knobs.unset("WINO_SK_GRID")
+    assert torch.equal(pkg.conv3x3_bn_relu(x, U, b, s), ref)
+
+
+def test_conv3x3_streamk_with_a_competing_stream(pkg, torch_dev, knobs):
+    """The same hazard without a forced grid: a second stream's launches occupy CUs, so part of the
+    headline launch's 256 workgroups start late.  Results must not move (bitwise), counters must be zero."""
+    torch, dev = torch_dev
+    knobs.set("WINO_3X3_ALGO", "big")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
+    x, w, s, b = mk(128, 16, 16, 256), mk(256, 256, 3, 3), mk(256), mk(256)
+    xs, ws, vs = mk(64, 16, 16, 128), mk(128, 128, 3, 3), mk(128)
+    U, Us = pkg.filter_transform_f2(w), pkg.filter_transform_f2(ws)
+    ref = pkg.conv3x3_bn_relu(x, U, b, s).clone()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                pkg.conv3x3_bn_relu(xs, Us, vs, vs)
+        outs = [pkg.conv3x3_bn_relu(x, U, b, s) for _ in range(5)]
+        for o in outs:
+            assert torch.equal(o, ref), rep
+    torch.cuda.synchronize()
+    assert pkg.tickets_in_use() == 0
+
+
 @pytest.mark.parametrize("N,H,W,C,K", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (5, 8, 12, 16, 64),
                                        (7, 2, 2, 8, 64), (2, 30, 6, 24, 192), (64, 28, 28, 128, 128),
                                        (9, 7, 7, 512, 512), (4, 1, 1, 8, 64), (3, 5, 8, 16, 64), (2, 13, 3, 40, 128)])

@@ -1,0 +1,51 @@
+"""Developer tool (GPU box): soak of the 3x3 throughput kernel's hand-offs.  For several shapes and forced
+grids, launches the layer back to back and compares every result bitwise with the first of its
+configuration (stream-K sums are added in segment order, so they must not move); under uneven load
+(a second stream runs another layer concurrently).  usage: python tools/soak.py [seconds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+pkg = ge.load_package()
+if os.environ.get("SOAK_LIB"): pkg.LIB_PATH = os.path.abspath(os.environ["SOAK_LIB"])   # A/B against another build of the library
+L = pkg.lib()
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+os.environ["WINO_3X3_ALGO"] = "big"
+torch.manual_seed(0)
+cfgs = []
+for (N, C, K, grid) in [(128, 256, 256, 0), (128, 128, 128, 0), (50, 64, 128, 56), (37, 128, 192, 200), (96, 256, 64, 97),
+                        (20, 512, 256, 0), (7, 64, 64, 13), (128, 256, 256, 333), (3, 256, 256, 48)]:
+    x = torch.rand(N, 16, 16, C, device=dev) - 0.5
+    U = pkg.filter_transform_f2(torch.rand(K, C, 3, 3, device=dev) - 0.5)
+    b, s = torch.rand(K, device=dev) - 0.5, torch.rand(K, device=dev) - 0.5
+    cfgs.append([N, C, K, grid, x, U, b, s, None])
+side = torch.cuda.Stream()
+xs = torch.rand(64, 16, 16, 128, device=dev); Us = pkg.filter_transform_f2(torch.rand(128, 128, 3, 3, device=dev)); vs = torch.rand(128, device=dev)
+use_side = os.environ.get("SOAK_SIDE", "1") != "0"
+t0, launches, bad = time.time(), 0, 0
+stats = {}
+while time.time() - t0 < budget:
+    for c in cfgs:
+        N, C, K, grid, x, U, b, s, ref = c
+        if grid: os.environ["WINO_SK_GRID"] = str(grid)
+        else: os.environ.pop("WINO_SK_GRID", None)
+        L.wino_debug_reload_knobs()
+        if use_side:
+            with torch.cuda.stream(side):          # uneven load from another stream (its own scratch)
+                for _ in range(3): pkg.conv3x3_bn_relu(xs, Us, vs, vs)
+        outs = [pkg.conv3x3_bn_relu(x, U, b, s) for _ in range(20)]
+        launches += 20
+        if ref is None:
+            c[8] = outs[0].clone(); ref = c[8]
+        for o in outs:
+            if not torch.equal(o, ref):
+                bad += 1
+                d = (o - ref).abs()
+                key = (N, C, K, grid)
+                st = stats.setdefault(key, [0, 0.0, 0, 0])
+                st[0] += 1; st[1] = max(st[1], float(d.max())); st[2] = max(st[2], int((d > 0).sum())); st[3] = max(st[3], int(torch.isnan(o).sum()))
+    torch.cuda.synchronize()
+for k, v in stats.items(): print("  differs", k, "times", v[0], "max |diff|", v[1], "max elements", v[2], "nan", v[3], "ref max", float(cfgs[[ (c[0],c[1],c[2],c[3]) for c in cfgs].index(k)][8].abs().max()))
+print("soak: %d launches in %.0f s, %d results differ from the first of their configuration" % (launches, time.time() - t0, bad))
+sys.exit(1 if bad else 0)
