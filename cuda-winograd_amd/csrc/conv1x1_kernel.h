@@ -25,6 +25,10 @@ namespace gemm1x1 {
 #define WINO_1X1_DMA0 4   // first step of a stage (of 14) that issues an LDS-DMA piece of the next one;
                           // tools/ablate_1x1: 0 / 2 / 4 / 6 within 1 % on all four reference shapes, 8 up to +9 %
 #endif
+#ifndef WINO_1X1_DIRECT_EPI
+#define WINO_1X1_DIRECT_EPI 1   // 1: transposed accumulators, 16-byte stores straight from registers; 0: round 1's LDS-staged rows
+#endif
+constexpr bool DIRECT_EPI = WINO_1X1_DIRECT_EPI != 0;
 constexpr int BM = 112;
 constexpr int WINO_INTERNAL_NO_BN = 1 << 16;   // not part of the public flag set
 constexpr int RB = BM / 16;  // 7 row blocks
@@ -145,7 +149,10 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   // Cached when the output is the padded input of a 3x3 layer (read again at once) and for short
   // K loops, which are bound by the stores themselves and lose the L2's write combining (with
   // streaming stores everywhere the 56x56 block, whose last layer is 64->256, went 522 -> 533 us).
-  const bool stream_out = !c_padded && Cin >= 4 * BK;
+#ifndef WINO_1X1_NT
+#define WINO_1X1_NT 1
+#endif
+  const bool stream_out = WINO_1X1_NT && !c_padded && Cin >= 4 * BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NBLK = Kout / BN;
   const int bid = blockIdx.x;
@@ -322,6 +329,10 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (ABLATE & 4) asm volatile("" ::"v"(a[t][j]), "v"(b[s][j]));
+        // DIRECT_EPI: the filter fragment is the MFMA's A operand and the pixel fragment its B operand (both are
+        // "one value per lane, index lane & 15, k = lane >> 4", so the swap is free): D = C^T, a lane then holds
+        // four CONSECUTIVE out-channels 16 w + 4 h + 0..3 of pixel rb*16 + r16 -- one 16-byte store, no staging.
+        else if (DIRECT_EPI) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][j], a[t][j], acc[rb], 0, 0, 0);
         else acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[s][j], acc[rb], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -344,14 +355,18 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     }
   }
 
-  // ---- epilogue: BN (+residual) (+ReLU).  C/D layout: col = lane&15, row = 4*(lane>>4)+i.
-  // The 112 x BN tile goes through LDS (the pipeline stages are free now) so that it leaves as
-  // whole rows -- 16 B per lane, 512 / 256 contiguous bytes per output row -- instead of 64-byte
-  // fragments written 4 bytes per lane; the residual is read the same way.
-  // Image [row][col] floats; the 16-float column group is XORed with (row>>2)&3 = the MFMA row
-  // group h, which keeps the ds_write_b32 of the four row groups on disjoint banks.
+  // ---- epilogue: BN (+residual) (+ReLU).
+  // DIRECT_EPI (round 2): the accumulators are C^T tiles (see the MFMA above): lane (r16, h) holds out-channels
+  // n0 + 16 w + 4 h + 0..3 of pixel rows m0 + rb*16 + r16, rb = 0..6 -- BN with four per-channel scales, then one
+  // 16-byte store per row block straight from registers (a store instruction covers 16 rows x 64 contiguous
+  // bytes); the residual is read the same way.  No LDS image, no barrier: a wave leaves as soon as its own
+  // MFMAs are done.  Round 1 staged the 112 x BN tile through LDS (two barriers, 28 ds_write_b32 + 7
+  // ds_read_b128 per lane) to store whole 256 / 512-byte rows; that path is kept under WINO_1X1_DIRECT_EPI=0:
+  // C/D layout col = lane&15, row = 4*(lane>>4)+i; the 112 x BN tile goes through LDS (the pipeline stages are
+  // free now) so that it leaves as whole rows -- 16 B per lane, 512 / 256 contiguous bytes per output row --
+  // image [row][col] floats, the 16-float column group XORed with (row>>2)&3 = the MFMA row group h.
+  if (!DIRECT_EPI || SK)
   __syncthreads();   // every wave is done with the pipeline stages; no LDS-DMA is in flight
-  float* img = (float*)smem;
   if (SK && !(k0 == 0 && len == nk)) {
     // Partial segment.  The tile is finished by whoever learns that all of its other segments
     // have been published: a range's last segment first looks at the tile's counter -- its
@@ -413,6 +428,51 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     }
     __syncthreads();   // everyone has read the ticket word before the image overwrites it
   }
+  if (DIRECT_EPI) {
+    if (ABLATE & 512) {   // price the stores: keep the accumulators (and with them the MFMAs) alive
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++) asm volatile("" ::"v"(acc[rb]));
+      continue;
+    }
+    const bool raw = flags & WINO_INTERNAL_NO_BN;   // plain GEMM: no scale / bias vectors at all
+    const int ch = n0 + 16 * w + 4 * h;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+    if (!raw) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) { sc[j] = bnScale[ch + j]; bi[j] = bnBias[ch + j]; }
+    }
+    auto store_rows = [&](auto stream_c) {
+#pragma unroll
+      for (int rb = 0; rb < RB; rb++) {
+        const long grow = m0 + rb * 16 + r16;
+        f32x4 val = sc * acc[rb] + bi;
+        if (relu && !add_res) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
+        }
+        if (grow < M) {
+          if (add_res) {
+            val += *(const f32x4*)(R + grow * Kout + ch);
+            if (relu) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
+            }
+          }
+          // c_padded: row = pixel (n, y, x) of the H x W map -> interior of [N][H+2][W+2][Kout]
+          // (its zero ring is written by the ring pass at the top of the kernel)
+          const long orow = c_padded ? padded_row(grow, pg) : grow;
+          if (decltype(stream_c)::value) __builtin_nontemporal_store(val, (f32x4*)(Cout + orow * Kout + ch));
+          else *(f32x4*)(Cout + orow * Kout + ch) = val;
+        }
+      }
+    };
+    // (two copies under one uniform branch, one per store form: inside a shared loop the optimizer folds the
+    //  two stores into one plain store)
+    if (stream_out) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
+    continue;
+  }
+  float* img = (float*)smem;
   {
     const int col = n0 + 16 * w + r16;
     const bool raw = flags & WINO_INTERNAL_NO_BN;   // plain GEMM: no scale / bias vectors at all

@@ -18,13 +18,12 @@ float run(const float* A, const float* B, const float* b, const float* s, float*
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&] { hipLaunchKernelGGL((conv1x1_bn_kernel<32, NW, AB>), dim3(grid), dim3(G::NT), G::LDS_BYTES, 0, A, B, b, s, (const float*)nullptr, C, M, Cin, Kout, 1, nMB, 0L, 0L, 0L, wino::gemm1x1::SkArgs{nullptr, nullptr}, wino::gemm1x1::make_padgeo(14, 14)); };
-  for (int i = 0; i < 5; i++) launch();
-  CK(hipDeviceSynchronize());
+  for (int i = 0; i < 300; i++) launch();   // clock ramp: a burst from an idle chip runs at 2.05 GHz
   CK(hipEventRecord(e0));
-  for (int i = 0; i < 20; i++) launch();
+  for (int i = 0; i < 100; i++) launch();
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  return ms * 50.f;
+  return ms * 10.f;
 }
 
 template <int NW>

@@ -1,4 +1,4 @@
-"""Developer tool (GPU box): soak of the 3x3 throughput kernel's hand-offs.  For several shapes and forced
+"""Developer tool (GPU box): soak of the stream-K hand-offs of both kernels.  For several shapes and forced
 grids, launches the layer back to back and compares every result bitwise with the first of its
 configuration (stream-K sums are added in segment order, so they must not move); under uneven load
 (a second stream runs another layer concurrently).  usage: python tools/soak.py [seconds]"""
@@ -20,6 +20,14 @@ for (N, C, K, grid) in [(128, 256, 256, 0), (128, 128, 128, 0), (50, 64, 128, 56
     U = pkg.filter_transform_f2(torch.rand(K, C, 3, 3, device=dev) - 0.5)
     b, s = torch.rand(K, device=dev) - 0.5, torch.rand(K, device=dev) - 0.5
     cfgs.append([N, C, K, grid, x, U, b, s, None])
+# 1x1 stream-K / split-K forms (M = N * 196 rows), automatic and forced grids (multiples of 8 and of the column blocks)
+cfg1 = []
+for (N, Cin, Kout, grid) in [(128, 1024, 256, 0), (128, 1024, 256, 512), (100, 512, 128, 0), (100, 512, 128, 320), (2, 1024, 256, 0),
+                             (160, 1024, 256, 0), (60, 2048, 512, 768)]:
+    A = torch.rand(N * 196, Cin, device=dev) - 0.5
+    Bm = torch.rand(Cin, Kout, device=dev) - 0.5
+    b, s = torch.rand(Kout, device=dev) - 0.5, torch.rand(Kout, device=dev) - 0.5
+    cfg1.append([N, Cin, Kout, grid, A, Bm, b, s, None])
 side = torch.cuda.Stream()
 xs = torch.rand(64, 16, 16, 128, device=dev); Us = pkg.filter_transform_f2(torch.rand(128, 128, 3, 3, device=dev)); vs = torch.rand(128, device=dev)
 use_side = os.environ.get("SOAK_SIDE", "1") != "0"
@@ -45,7 +53,30 @@ while time.time() - t0 < budget:
                 key = (N, C, K, grid)
                 st = stats.setdefault(key, [0, 0.0, 0, 0])
                 st[0] += 1; st[1] = max(st[1], float(d.max())); st[2] = max(st[2], int((d > 0).sum())); st[3] = max(st[3], int(torch.isnan(o).sum()))
+    for c in cfg1:
+        N, Cin, Kout, grid, A, Bm, b, s, ref = c
+        if grid: os.environ["WINO_1X1_SK_GRID"] = str(grid)
+        else: os.environ.pop("WINO_1X1_SK_GRID", None)
+        L.wino_debug_reload_knobs()
+        if use_side:
+            with torch.cuda.stream(side):
+                for _ in range(3): pkg.conv3x3_bn_relu(xs, Us, vs, vs)
+        outs = [pkg.conv1x1_bn(A, Bm, b, s, True) for _ in range(10)]
+        launches += 10
+        if ref is None:
+            c[8] = outs[0].clone(); ref = c[8]
+            want = torch.relu((A.double() @ Bm.double()) * s.double() + b.double())
+            err = float((ref.double() - want).abs().max() / want.abs().max())
+            assert err < 2e-5, ("1x1 first result wrong", N, Cin, Kout, grid, err)
+        for o in outs:
+            if not torch.equal(o, ref):
+                bad += 1
+                st = stats.setdefault(("1x1", N, Cin, Kout, grid), [0, 0.0, 0, 0])
+                d = (o - ref).abs()
+                st[0] += 1; st[1] = max(st[1], float(d.max())); st[2] = max(st[2], int((d > 0).sum())); st[3] = max(st[3], int(torch.isnan(o).sum()))
+    os.environ.pop("WINO_1X1_SK_GRID", None)
     torch.cuda.synchronize()
-for k, v in stats.items(): print("  differs", k, "times", v[0], "max |diff|", v[1], "max elements", v[2], "nan", v[3], "ref max", float(cfgs[[ (c[0],c[1],c[2],c[3]) for c in cfgs].index(k)][8].abs().max()))
+for k, v in stats.items(): print("  differs", k, "times", v[0], "max |diff|", v[1], "max elements", v[2], "nan", v[3])
+print("ticket counters in use at the end:", pkg.tickets_in_use())
 print("soak: %d launches in %.0f s, %d results differ from the first of their configuration" % (launches, time.time() - t0, bad))
 sys.exit(1 if bad else 0)
