@@ -7,6 +7,8 @@
 //   8 skip the per-chunk wait+barrier 16 stamp the main loop (in-kernel clock)
 //   32 skip the A-path reads+transform 64 skip the B-fragment reads  512 skip the output stores
 //   1024 skip the stream-K slab hand-off (partial segments are dropped)
+//   32768 timeline (tools/ablate_fused ... t): s_memrealtime (100 MHz, chip-wide) at kernel entry, first MFMA,
+//         start of the last epilogue and exit of every workgroup, 8 uint64 per workgroup in prm.dbg
 //
 // Work decomposition: the launch's work is a set of "chunk iterations"
 //   (item, chunk),  item = (tile block, k block),  chunk = 8 input channels,
@@ -183,6 +185,12 @@ wino_f2_fused_kernel(const FusedParams prm) {
   const int G = gridDim.x;
   const int lg = (int)(blockIdx.x & 7) * (G >> 3) + ((int)(blockIdx.x & 7) < (G & 7) ? (int)(blockIdx.x & 7) : (G & 7)) +
                  (int)(blockIdx.x >> 3);
+  if (ABLATE & 32768) {
+    if (threadIdx.x == 0) {
+      prm.dbg[(size_t)lg * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+      prm.dbg[(size_t)lg * 8 + 4] = __builtin_amdgcn_s_memtime();
+    }
+  }
   // tail: items ndp*G .. , (sk_q * G + sk_rem) chunk iterations in item-major order; then the rounds
   const int tail_item0 = ndp * G;
   const unsigned t_begin = __builtin_amdgcn_readfirstlane(sk_start(lg, sk_q, sk_rem, G));
@@ -491,6 +499,9 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #pragma unroll
     for (int j = 0; j < 4; j++) a_adr[k][j] ^= RAW_BYTES;   // iteration 0 reads raw_1 from R1
 #endif
+  if (ABLATE & 32768) {
+    if (tid == 0) prm.dbg[(size_t)lg * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
   if (ABLATE & 16) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime)
     // The start stamps go to memory at once: kept in SGPRs across the main loop (which has none to
     // spare) they pushed loop-carried scalars into VGPRs and the build ran 15 % slower than the
@@ -782,7 +793,23 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #pragma unroll
       for (int q = 0; q < 8; q++)
         slab_store16(y[q >> 1][q & 1], rsrc_slab, slab_voff + q * 1024, my_slot * SLAB_BYTES);
-      if (!last_of_range) {
+      // When is this segment's ticket drawn?  Whoever draws an item's last ticket gathers it, and a gather is
+      // 3-5 us of work that only an epilogue can do:
+      //  * the range's last segment: now (there is no later epilogue);
+      //  * a segment that STARTS its item in a range that already had a partial segment (a "straddler": its
+      //    range crosses an item boundary, so it pays one epilogue more than its neighbours): now.  Deferred to
+      //    the final epilogue it was always its item's last arriver: the workgroups that are the slowest anyway
+      //    gathered at the very end of the launch (round 1: exits spread over 106 .. 117.6 us at 256 channels,
+      //    N = 128; tools/ablate_fused 256 256 t).  The wait costs little: the next iteration's vmcnt(0)
+      //    would have waited for the same stores;
+      //  * any other partial segment: at the next epilogue, when its stores have long drained.  The only tail
+      //    segment of a range that lies inside one item thus draws at the final epilogue: these workgroups have
+      //    the slack (no second partial epilogue), and they become the gatherers of the 3-segment items.
+      // 256 channels: N = 128 118.7 -> 117.7 us, N = 96 98.5 -> 94.8; elsewhere within +-0.7 %.  (On top of this, the
+      // gather's slabs requested all at once, the deferred item's before this segment's own finalize, with the
+      // accumulators re-zeroed at the end of the epilogue to make room: 0.1-0.6 % slower everywhere.)
+      const bool now = last_of_range || ((seg_kind & 2) && job1 >= 0);
+      if (!now) {
         pend_item = c_item;        // ticket deferred to the next segment's epilogue
       } else {
         wait_vmem_all();           // this wave's write-through stores have left ...
@@ -957,6 +984,10 @@ wino_f2_fused_kernel(const FusedParams prm) {
       // the segment's last iteration was it-1: raw stage R[it & 1] and filter stage U[us_last] are free
       const bool last_of_range = it == L;
       if (ABLATE & 2048) { const unsigned long long t = stamp(); st_comp += t - st_prev; st_prev = t; }
+      if ((ABLATE & 32768) && last_of_range && tid == 0) {
+        KernargPtr kp = kernarg();
+        kp->dbg[(size_t)lg * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+      }
       epilogue(last_of_range, (it & 1) * RAW_BYTES, N_RSTAGE * RAW_BYTES + us_last * U_BYTES);
       if (ABLATE & 2048) { const unsigned long long t = stamp(); st_epi += t - st_prev; st_prev = t; }
       if (last_of_range) break;
@@ -984,6 +1015,13 @@ wino_f2_fused_kernel(const FusedParams prm) {
       dbg[4] = st_ph[1];
       dbg[5] = st_ph[2];
       dbg[6] = st_ph[3];
+    }
+  }
+  if (ABLATE & 32768) {
+    if (tid == 0) {
+      KernargPtr kp = kernarg();
+      kp->dbg[(size_t)lg * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+      kp->dbg[(size_t)lg * 8 + 5] = __builtin_amdgcn_s_memtime();
     }
   }
   if (ABLATE & 16) {

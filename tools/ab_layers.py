@@ -51,7 +51,8 @@ print(f"{'us per launch':34s}" + "  ".join(f"{os.path.basename(os.path.dirname(o
 N = int(os.environ.get("AB_N", "128"))
 M = N * 196
 rnd = lambda *s: (torch.rand(*s, device=dev) - 0.5)
-for (Cin, Kout, relu) in ((512, 128, 1), (128, 512, 0), (1024, 256, 1), (256, 1024, 0), (64, 256, 0), (2048, 512, 1)):
+only = os.environ.get("AB_ONLY", "")   # "3x3" / "1x1": just those layers
+for (Cin, Kout, relu) in ((512, 128, 1), (128, 512, 0), (1024, 256, 1), (256, 1024, 0), (64, 256, 0), (2048, 512, 1)) if only != "3x3" else ():
     A, B, b, s, C = rnd(M, Cin), rnd(Cin, Kout), rnd(Kout), rnd(Kout), torch.empty(M, Kout, device=dev)
     fns = [(lambda L=L: L.wino_conv1x1_bn(A.data_ptr(), B.data_ptr(), b.data_ptr(), s.data_ptr(), C.data_ptr(), M, Cin, Kout, relu, st())) for _, L in libs]
     outs = []
@@ -59,15 +60,16 @@ for (Cin, Kout, relu) in ((512, 128, 1), (128, 512, 0), (1024, 256, 1), (256, 10
         C.fill_(float("nan")); assert f() == 0; outs.append(C.clone())
     same = all(torch.equal(o, outs[0]) for o in outs)
     bench(f"1x1 {Cin}->{Kout} N={N}{'' if same else '  (DIFFER)'}", fns)
-# the block's last layer: 256 -> 1024 + skip + ReLU, A padded
-Apad, B, b, s, R, C = rnd(N, 16, 16, 256), rnd(256, 1024), rnd(1024), rnd(1024), rnd(M, 1024), torch.empty(M, 1024, device=dev)
-fns = [(lambda L=L: L.wino_conv1x1_bn_ex(Apad.data_ptr(), B.data_ptr(), b.data_ptr(), s.data_ptr(), R.data_ptr(), C.data_ptr(), M, 256, 1024, 1 | 2 | 8, st())) for _, L in libs]
-bench("1x1 256->1024 + skip (A padded)", fns)
-# the block's first layer: 1024 -> 256, C padded
-A, B, b, s, Cp = rnd(M, 1024), rnd(1024, 256), rnd(256), rnd(256), torch.empty(N, 16, 16, 256, device=dev)
-fns = [(lambda L=L: L.wino_conv1x1_bn_ex(A.data_ptr(), B.data_ptr(), b.data_ptr(), s.data_ptr(), None, Cp.data_ptr(), M, 1024, 256, 1 | 4, st())) for _, L in libs]
-bench("1x1 1024->256 (C padded)", fns)
-for Cc in (128, 256):
+if only != "3x3":
+    # the block's last layer: 256 -> 1024 + skip + ReLU, A padded
+    Apad, B, b, s, R, C = rnd(N, 16, 16, 256), rnd(256, 1024), rnd(1024), rnd(1024), rnd(M, 1024), torch.empty(M, 1024, device=dev)
+    fns = [(lambda L=L: L.wino_conv1x1_bn_ex(Apad.data_ptr(), B.data_ptr(), b.data_ptr(), s.data_ptr(), R.data_ptr(), C.data_ptr(), M, 256, 1024, 1 | 2 | 8, st())) for _, L in libs]
+    bench("1x1 256->1024 + skip (A padded)", fns)
+    # the block's first layer: 1024 -> 256, C padded
+    A, B, b, s, Cp = rnd(M, 1024), rnd(1024, 256), rnd(256), rnd(256), torch.empty(N, 16, 16, 256, device=dev)
+    fns = [(lambda L=L: L.wino_conv1x1_bn_ex(A.data_ptr(), B.data_ptr(), b.data_ptr(), s.data_ptr(), None, Cp.data_ptr(), M, 1024, 256, 1 | 4, st())) for _, L in libs]
+    bench("1x1 1024->256 (C padded)", fns)
+for Cc in (128, 256) if only != "1x1" else ():
     x, w, b, s = rnd(N, 16, 16, Cc), rnd(Cc, Cc, 3, 3), rnd(Cc), rnd(Cc)
     U, out = torch.empty(16 * Cc * Cc, device=dev), torch.empty(N, 16, 16, Cc, device=dev)
     libs[0][1].wino_filter_transform_f2(w.data_ptr(), U.data_ptr(), Cc, Cc, st())

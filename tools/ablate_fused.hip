@@ -78,6 +78,41 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 3 && argv[3][0] == 't') {   // timeline: where a launch's wall time goes (chip-wide 100 MHz stamps)
+    const int N = argc > 4 ? atoi(argv[4]) : 128;
+    run<0>(in, U, b, s, out, N, C, K, 3000);
+    const float us_prod = run<0>(in, U, b, s, out, N, C, K, 200);
+    const float us_tl = run<32768>(in, U, b, s, out, N, C, K, 200);   // the stamps of the LAST of 200 back-to-back launches stay
+    const int wgs = grid_for(N, K);
+    std::vector<unsigned long long> st((size_t)wgs * 8);
+    CK(hipMemcpy(st.data(), g_dbg, st.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, tend = 0;
+    std::vector<double> entry, first, lastep, exitt, pro, epi;
+    for (int l = 0; l < wgs; l++) { t0 = std::min(t0, st[8 * l]); tend = std::max(tend, st[8 * l + 3]); }
+    for (int l = 0; l < wgs; l++) {
+      entry.push_back((st[8 * l] - t0) * 0.01); first.push_back((st[8 * l + 1] - t0) * 0.01);
+      lastep.push_back((st[8 * l + 2] - t0) * 0.01); exitt.push_back((st[8 * l + 3] - t0) * 0.01);
+      pro.push_back((st[8 * l + 1] - st[8 * l]) * 0.01); epi.push_back((st[8 * l + 3] - st[8 * l + 2]) * 0.01);
+    }
+    auto pr = [&](const char* name, std::vector<double> v) {
+      std::sort(v.begin(), v.end());
+      printf("  %-34s min %7.2f  p10 %7.2f  median %7.2f  p90 %7.2f  max %7.2f us\n", name, v[0], v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+    };
+    printf("%s C=%d N=%d grid=%d: product %.2f us per launch, timeline build %.2f; first entry -> last exit %.2f us (10 ns ticks)\n", argv[0], C, N, wgs, us_prod, us_tl, (tend - t0) * 0.01);
+    pr("entry (after the first entry)", entry); pr("first MFMA", first); pr("start of the last epilogue", lastep); pr("exit", exitt);
+    pr("entry -> first MFMA", pro); pr("last epilogue -> exit", epi);
+    if (argc > 5) {   // per workgroup, with the shape of its tail range
+      const int nTB = (N * 49 + TB - 1) / TB, nch = C / 8;
+      const unsigned items = (unsigned)nTB * (K / KB), Tt = (items % wgs) * nch, q = Tt / wgs, rem = Tt % wgs;
+      printf("lg first_chunk len segs | first_mfma last_epi_start exit epi_len\n");
+      for (int l = 0; l < wgs; l++) {
+        const unsigned a = sk_start(l, q, rem, wgs), b2 = sk_start(l + 1, q, rem, wgs);
+        const int segs = b2 > a ? (int)((b2 - 1) / nch - a / nch + 1) : 0;
+        printf("%3d %2u %2u %d | %6.2f %7.2f %7.2f %5.2f\n", l, a % nch, b2 - a, segs, first[l], lastep[l], exitt[l], epi[l]);
+      }
+    }
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 'h') {   // timing only: what the parts of the A path cost
     run<0>(in, U, b, s, out, 128, C, K, 3000);
     for (int i = 0; i < 3; i++)
