@@ -173,7 +173,7 @@ static int launch_1x1(const float* A, const float* B, const float* bnBias, const
   const long long tiles = (long long)nMB * (Kout / G::BN);
   const int Gsk = batch == 1 ? sk1_grid(tiles, Cin / BK, cus, Kout / G::BN, NW == 4) : 0;
   if (Gsk) {
-    SkArgs sk{nullptr, nullptr};
+    SkArgs sk{nullptr, nullptr, nullptr};
     if (int rc = sk_scratch(dev, s, (size_t)2 * Gsk * NW * RB * 1024, (size_t)tiles, &sk.slabs, &sk.tickets)) return rc;
     if (prepare_only) return WINO_OK;
     hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW, 0, true>), dim3(Gsk), dim3(G::NT), G::LDS_BYTES, s, A, B,
@@ -183,7 +183,7 @@ static int launch_1x1(const float* A, const float* B, const float* bnBias, const
   if (prepare_only) return WINO_OK;
   const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
   hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW>), dim3(grid, batch), dim3(G::NT), G::LDS_BYTES, s, A, B,
-                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC, SkArgs{nullptr, nullptr}, pg);
+                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC, SkArgs{nullptr, nullptr, nullptr}, pg);
   return launch_status("conv1x1_bn_kernel");
 }
 

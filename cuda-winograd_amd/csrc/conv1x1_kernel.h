@@ -25,6 +25,9 @@ namespace gemm1x1 {
 #define WINO_1X1_DMA0 4   // first step of a stage (of 14) that issues an LDS-DMA piece of the next one;
                           // tools/ablate_1x1: 0 / 2 / 4 / 6 within 1 % on all four reference shapes, 8 up to +9 %
 #endif
+#ifndef WINO_1X1_PROLOGUE_PRIO
+#define WINO_1X1_PROLOGUE_PRIO 1
+#endif
 #ifndef WINO_1X1_DIRECT_EPI
 #define WINO_1X1_DIRECT_EPI 1   // 1: transposed accumulators, 16-byte stores straight from registers; 0: round 1's LDS-staged rows
 #endif
@@ -122,6 +125,7 @@ struct Cfg {
 struct SkArgs {
   float* slabs;
   unsigned* tickets;
+  unsigned long long* dbg;   // timeline build only (ABLATE & 32768, tools/ablate_1x1 t): 8 uint64 per workgroup
 };
 
 // Resident waves per SIMD the LDS footprint allows -- two 8-wave workgroups (60 KB each) or three
@@ -157,8 +161,20 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   const int NBLK = Kout / BN;
   const int bid = blockIdx.x;
   const int nk = Cin / BK;
+  // A new workgroup's waves are the youngest on their SIMDs, and the arbiter serves the oldest first: beside two
+  // resident workgroups in their MFMA loops, the address set-up below took 2.5 us (median; 6.7 us at the 90th
+  // percentile) from entry to the first LDS-DMA on the 128->512 layer (tools/ablate_1x1 t) -- time in which the
+  // slot holds LDS and registers and feeds nothing.  High priority until the first stage is requested.
+  if (WINO_1X1_PROLOGUE_PRIO) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (ABLATE & 32768) {   // timeline: chip-wide 100 MHz stamps at entry / first MFMA / start of the last epilogue / exit
+    if (threadIdx.x == 0) {
+      sk.dbg[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+      // which CU: HW_REG_HW_ID (cu bits 8-11, se bits 13-15) and HW_REG_XCC_ID
+      sk.dbg[(size_t)blockIdx.x * 8 + 4] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
+  }
   if (c_padded && !(ABLATE & 512)) {
     // ring pass: the padded output's zero ring (the 3x3 layer's padding) as a flat list of
     // 16-byte units -- images x ring pixels x Kout/4 units -- split over the grid
@@ -208,6 +224,8 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   }
   const int r16 = lane & 15, h = lane >> 4;
   bool first_seg = true;
+  bool first_seg_stamp = true;
+  unsigned long long stamp_first = 0;
 #pragma unroll 1
   while (u < uend) {
   const int mb = (int)(u / nk);
@@ -288,6 +306,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
 
 #pragma unroll
   for (int p = 0; p < PIECES; p++) issue_piece(0, (unsigned)k0 * a_kstep, (unsigned)k0 * b_kstep, p);
+  if (WINO_1X1_PROLOGUE_PRIO) __builtin_amdgcn_s_setprio(0);
 
   // `more` (is there a k-step after this one to fetch) is a compile-time property of the body: the
   // last iteration of a segment is peeled below, so no piece is issued behind a branch
@@ -338,6 +357,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  if ((ABLATE & 32768) && stamp_first == 0) stamp_first = __builtin_amdgcn_s_memrealtime();   // the first stage is about to be waited for
   {
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -347,6 +367,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       body(P0{}, std::true_type{}, it);
       body(P1{}, std::true_type{}, it + 1);
     }
+
     if (it + 2 == len) {
       body(P0{}, std::true_type{}, it);
       body(P1{}, std::false_type{}, it + 1);
@@ -355,6 +376,12 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     }
   }
 
+  if (ABLATE & 32768) {
+    if (threadIdx.x == 0) {
+      sk.dbg[(size_t)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();                 // overwritten by every segment: the last one stays
+      if (first_seg_stamp) sk.dbg[(size_t)blockIdx.x * 8 + 1] = stamp_first;
+    }
+  }
   // ---- epilogue: BN (+residual) (+ReLU).
   // DIRECT_EPI (round 2): the accumulators are C^T tiles (see the MFMA above): lane (r16, h) holds out-channels
   // n0 + 16 w + 4 h + 0..3 of pixel rows m0 + rb*16 + r16, rb = 0..6 -- BN with four per-channel scales, then one
@@ -526,6 +553,9 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     else store_rows(std::false_type{});
   }
   }   // segments
+  if (ABLATE & 32768) {
+    if (threadIdx.x == 0) sk.dbg[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 

@@ -14,7 +14,7 @@ float run(const float* A, const float* B, const float* b, const float* s, float*
   const int nMB = (int)((M + BM - 1) / BM);
   const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  auto launch = [&] { hipLaunchKernelGGL((conv1x1_bn_kernel<32, NW, 0>), dim3(grid), dim3(G::NT), lds, 0, A, B, b, s, (const float*)nullptr, C, M, Cin, Kout, 1, nMB, 0L, 0L, 0L, SkArgs{nullptr, nullptr}, make_padgeo(14, 14)); };
+  auto launch = [&] { hipLaunchKernelGGL((conv1x1_bn_kernel<32, NW, 0>), dim3(grid), dim3(G::NT), lds, 0, A, B, b, s, (const float*)nullptr, C, M, Cin, Kout, 1, nMB, 0L, 0L, 0L, SkArgs{nullptr, nullptr, nullptr}, make_padgeo(14, 14)); };
   for (int i = 0; i < 10; i++) launch();
   CK(hipDeviceSynchronize());
   float best = 1e9f;
