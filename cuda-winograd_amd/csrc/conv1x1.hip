@@ -152,19 +152,35 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_f
   return (t_sk2 < t_sk1 ? t_sk2 : t_sk1) < 0.99 * t_plain ? (int)G : 0;
 }
 
+template <int BK, int NW, bool RES = false>
+static int launch_1x1_res(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                          const float* R, float* C, long M, int Cin, int Kout, int flags, int nMB,
+                          hipStream_t s, int batch, long batchA, long batchB, long batchC,
+                          bool prepare_only, PadGeo pg);
+
 template <int BK, int NW>
 static int launch_1x1(const float* A, const float* B, const float* bnBias, const float* bnScale,
                       const float* R, float* C, long M, int Cin, int Kout, int flags, int nMB,
                       hipStream_t s, int batch = 1, long batchA = 0, long batchB = 0, long batchC = 0,
                       bool prepare_only = false, PadGeo pg = make_padgeo(WINO_PQ, WINO_PQ)) {
+  if (flags & WINO_ADD_RESIDUAL)
+    return launch_1x1_res<BK, NW, true>(A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, s, batch, batchA, batchB, batchC, prepare_only, pg);
+  return launch_1x1_res<BK, NW, false>(A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, s, batch, batchA, batchB, batchC, prepare_only, pg);
+}
+
+template <int BK, int NW, bool RES>
+static int launch_1x1_res(const float* A, const float* B, const float* bnBias, const float* bnScale,
+                          const float* R, float* C, long M, int Cin, int Kout, int flags, int nMB,
+                          hipStream_t s, int batch, long batchA, long batchB, long batchC,
+                          bool prepare_only, PadGeo pg) {
   using G = Cfg<BK, NW>;
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
   WINO_HIP(hipGetDevice(&dev));
   if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
-    WINO_HIP(hipFuncSetAttribute((const void*)(conv1x1_bn_kernel<BK, NW>),
+    WINO_HIP(hipFuncSetAttribute((const void*)(conv1x1_bn_kernel<BK, NW, 0, false, RES>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    WINO_HIP(hipFuncSetAttribute((const void*)(conv1x1_bn_kernel<BK, NW, 0, true>),
+    WINO_HIP(hipFuncSetAttribute((const void*)(conv1x1_bn_kernel<BK, NW, 0, true, RES>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_done.fetch_or(1ull << (dev & 63));
   }
@@ -176,13 +192,13 @@ static int launch_1x1(const float* A, const float* B, const float* bnBias, const
     SkArgs sk{nullptr, nullptr, nullptr};
     if (int rc = sk_scratch(dev, s, (size_t)2 * Gsk * NW * RB * 1024, (size_t)tiles, &sk.slabs, &sk.tickets)) return rc;
     if (prepare_only) return WINO_OK;
-    hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW, 0, true>), dim3(Gsk), dim3(G::NT), G::LDS_BYTES, s, A, B,
+    hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW, 0, true, RES>), dim3(Gsk), dim3(G::NT), G::LDS_BYTES, s, A, B,
                        bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, 0L, 0L, 0L, sk, pg);
     return launch_status("conv1x1_bn_kernel (stream-K)");
   }
   if (prepare_only) return WINO_OK;
   const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
-  hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW>), dim3(grid, batch), dim3(G::NT), G::LDS_BYTES, s, A, B,
+  hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW, 0, false, RES>), dim3(grid, batch), dim3(G::NT), G::LDS_BYTES, s, A, B,
                      bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC, SkArgs{nullptr, nullptr, nullptr}, pg);
   return launch_status("conv1x1_bn_kernel");
 }

@@ -28,10 +28,6 @@ namespace gemm1x1 {
 #ifndef WINO_1X1_PROLOGUE_PRIO
 #define WINO_1X1_PROLOGUE_PRIO 1
 #endif
-#ifndef WINO_1X1_DIRECT_EPI
-#define WINO_1X1_DIRECT_EPI 1   // 1: transposed accumulators, 16-byte stores straight from registers; 0: round 1's LDS-staged rows
-#endif
-constexpr bool DIRECT_EPI = WINO_1X1_DIRECT_EPI != 0;
 constexpr int BM = 112;
 constexpr int WINO_INTERNAL_NO_BN = 1 << 16;   // not part of the public flag set
 constexpr int RB = BM / 16;  // 7 row blocks
@@ -131,7 +127,10 @@ struct SkArgs {
 // Resident waves per SIMD the LDS footprint allows -- two 8-wave workgroups (60 KB each) or three
 // 4-wave ones (44 KB) per CU -- stated to the register allocator, which otherwise takes the
 // freedom of 256 VGPRs and halves the residency (tests/test_build_budget.py).
-template <int BK, int NW, int ABLATE = 0, bool SK = false>
+// RES = the launch adds a residual (WINO_ADD_RESIDUAL): a compile-time property, because the two epilogues in one
+// kernel cost the one without residual 2-5 % (256->1024 99.6 -> 101.3 us, 64->256 14.1 -> 14.9) through nothing but
+// their presence -- register allocation and code layout of the rest.
+template <int BK, int NW, int ABLATE = 0, bool SK = false, bool RES = false>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3)
 conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                   const float* __restrict__ bnBias, const float* __restrict__ bnScale,
@@ -145,7 +144,8 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   Cout += (size_t)blockIdx.y * batchC;
   constexpr int BN = G::BN;
   const bool relu = flags & WINO_RELU, a_padded = flags & WINO_A_PADDED;
-  const bool c_padded = flags & WINO_C_PADDED, add_res = flags & WINO_ADD_RESIDUAL;
+  const bool c_padded = flags & WINO_C_PADDED;
+  constexpr bool add_res = RES;   // (the host picks the instantiation from flags & WINO_ADD_RESIDUAL)
   // Output stores: non-temporal when the output is written once and the layer is MFMA-bound (a K
   // loop of at least 4 steps) -- the L2 then stays with the A / B lines other workgroups re-read.
   // Old and new libraries interleaved: 512->128 31.95 -> 31.1 us, 128->512 36.25 -> 35.6, 1024->256
@@ -348,11 +348,10 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (ABLATE & 4) asm volatile("" ::"v"(a[t][j]), "v"(b[s][j]));
-        // DIRECT_EPI: the filter fragment is the MFMA's A operand and the pixel fragment its B operand (both are
+        // The filter fragment is the MFMA's A operand and the pixel fragment its B operand (both are
         // "one value per lane, index lane & 15, k = lane >> 4", so the swap is free): D = C^T, a lane then holds
         // four CONSECUTIVE out-channels 16 w + 4 h + 0..3 of pixel rb*16 + r16 -- one 16-byte store, no staging.
-        else if (DIRECT_EPI) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][j], a[t][j], acc[rb], 0, 0, 0);
-        else acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[s][j], acc[rb], 0, 0, 0);
+        else acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][j], a[t][j], acc[rb], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -383,16 +382,28 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     }
   }
   // ---- epilogue: BN (+residual) (+ReLU).
-  // DIRECT_EPI (round 2): the accumulators are C^T tiles (see the MFMA above): lane (r16, h) holds out-channels
-  // n0 + 16 w + 4 h + 0..3 of pixel rows m0 + rb*16 + r16, rb = 0..6 -- BN with four per-channel scales, then one
-  // 16-byte store per row block straight from registers (a store instruction covers 16 rows x 64 contiguous
-  // bytes); the residual is read the same way.  No LDS image, no barrier: a wave leaves as soon as its own
-  // MFMAs are done.  Round 1 staged the 112 x BN tile through LDS (two barriers, 28 ds_write_b32 + 7
-  // ds_read_b128 per lane) to store whole 256 / 512-byte rows; that path is kept under WINO_1X1_DIRECT_EPI=0:
-  // C/D layout col = lane&15, row = 4*(lane>>4)+i; the 112 x BN tile goes through LDS (the pipeline stages are
-  // free now) so that it leaves as whole rows -- 16 B per lane, 512 / 256 contiguous bytes per output row --
-  // image [row][col] floats, the 16-float column group XORed with (row>>2)&3 = the MFMA row group h.
-  if (!DIRECT_EPI || SK)
+  // The accumulators are C^T tiles (see the MFMA above): lane (r16, h) holds out-channels n0 + 16 w + 4 h + 0..3 of
+  // pixel rows m0 + rb*16 + r16, rb = 0..6 -- BN with four per-channel scales per lane.
+  //  * No residual: one 16-byte store per row block straight from registers (a store instruction covers 16 rows x
+  //    64 contiguous bytes).  No LDS image, no barrier: a wave leaves as soon as its own MFMAs are done.  (Round 1
+  //    staged every tile through LDS -- two barriers, 28 ds_write_b32 + 7 ds_read_b128 per lane -- to store whole
+  //    256 / 512-byte rows: 128->512 34.3 -> 31.0 us, 64->256 15.5 -> 14.5 without it.)
+  //  * With a residual: the 112 x BN tile goes through LDS (the pipeline stages are free now; one ds_write_b128 per
+  //    row block) and leaves as whole rows -- 16 B per lane, 512 / 256 contiguous bytes per row -- with the skip
+  //    tensor read the same way.  Read 64 bytes per row and wave, the skip tensor's 128-byte lines are fetched by
+  //    two waves at different times; inside the bottleneck block, where that tensor comes from HBM (a repeated
+  //    stand-alone launch finds it in the Infinity Cache), the last layer went 116.6 -> 123.6 us and 252.8 ->
+  //    273.1 MB per launch that way.  Image [row][col] floats, the 16-float column group XORed with (row>>2)&3.
+  constexpr bool direct_epi = !add_res;
+  // (opaque copies for the staged path: everything in it that only depends on the tile's position and the lane id
+  //  would otherwise be computed before the main loop and carried across it -- at 128 VGPRs that means scratch
+  //  spills.  The direct path keeps its hoistable form: made opaque too, 256->1024 100.2 -> 102.0 us, 64->256 +3.6 %.)
+  long m0_e = m0;
+  int lane_e = lane;
+  asm volatile("" : "+s"(m0_e));
+  asm volatile("" : "+v"(lane_e));
+  const int r16_e = lane_e & 15, h_e = lane_e >> 4;
+  if (!direct_epi || SK)
   __syncthreads();   // every wave is done with the pipeline stages; no LDS-DMA is in flight
   if (SK && !(k0 == 0 && len == nk)) {
     // Partial segment.  The tile is finished by whoever learns that all of its other segments
@@ -455,7 +466,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     }
     __syncthreads();   // everyone has read the ticket word before the image overwrites it
   }
-  if (DIRECT_EPI) {
+  if (direct_epi) {
     if (ABLATE & 512) {   // price the stores: keep the accumulators (and with them the MFMAs) alive
 #pragma unroll
       for (int rb = 0; rb < RB; rb++) asm volatile("" ::"v"(acc[rb]));
@@ -473,18 +484,11 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       for (int rb = 0; rb < RB; rb++) {
         const long grow = m0 + rb * 16 + r16;
         f32x4 val = sc * acc[rb] + bi;
-        if (relu && !add_res) {
+        if (relu) {
 #pragma unroll
           for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
         }
         if (grow < M) {
-          if (add_res) {
-            val += *(const f32x4*)(R + grow * Kout + ch);
-            if (relu) {
-#pragma unroll
-              for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
-            }
-          }
           // c_padded: row = pixel (n, y, x) of the H x W map -> interior of [N][H+2][W+2][Kout]
           // (its zero ring is written by the ring pass at the top of the kernel)
           const long orow = c_padded ? padded_row(grow, pg) : grow;
@@ -501,18 +505,17 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   }
   float* img = (float*)smem;
   {
-    const int col = n0 + 16 * w + r16;
     const bool raw = flags & WINO_INTERNAL_NO_BN;   // plain GEMM: no scale / bias vectors at all
-    const float sc = raw ? 1.f : bnScale[col], bi = raw ? 0.f : bnBias[col];
-    float* wr = img + (4 * h) * BN + ((16 * w + r16) ^ (h << 4));
+    const int cl = 16 * w + 4 * h_e;                   // this lane's four columns inside the tile
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+    if (!raw) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) { sc[j] = bnScale[n0 + cl + j]; bi[j] = bnBias[n0 + cl + j]; }
+    }
 #pragma unroll
     for (int rb = 0; rb < RB; rb++) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        float y = sc * acc[rb][i] + bi;
-        if (relu && !add_res) y = fmaxf(y, 0.f);
-        wr[(rb * 16 + i) * BN] = y;
-      }
+      const int row = rb * 16 + r16_e;
+      *(f32x4*)(img + row * BN + (cl ^ (((row >> 2) & 3) << 4))) = sc * acc[rb] + bi;   // (ReLU after the skip is added)
     }
   }
   __syncthreads();
@@ -522,16 +525,16 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     constexpr int RPI = 64 / LPR;        // rows per store instruction
     constexpr int RPW = BM / NW;         // rows per wave
     static_assert(RPW % RPI == 0, "rows per wave must be a whole number of store instructions");
-    const int c4 = (lane % LPR) * 4;
+    const int c4 = (lane_e % LPR) * 4;
     // Two copies of the row loop under one uniform branch, one per store form: inside a shared
     // loop the optimizer folds the two stores into one plain store, and an opaque pointer that
     // prevents that costs the cached form 1-2 % on the short-K layers.
     auto store_rows = [&](auto stream_c) {
 #pragma unroll
       for (int k = 0; k < RPW / RPI; k++) {
-        const int row = w * RPW + k * RPI + lane / LPR;
+        const int row = w * RPW + k * RPI + lane_e / LPR;
         f32x4 val = *(const f32x4*)(img + row * BN + (c4 ^ (((row >> 2) & 3) << 4)));
-        const long grow = m0 + row;
+        const long grow = m0_e + row;
         if (grow < M) {
           if (add_res) {
             const f32x4 r = *(const f32x4*)(R + grow * Kout + n0 + c4);

@@ -11,7 +11,7 @@ What is asserted: the VGPR budget and occupancy; no VGPR spill (scratch memory) 
 and at most a handful, outside the loops, in the GEMM; and no spill code of either kind -- v_readlane / v_writelane for SGPRs parked in VGPR lanes, scratch_load /
 scratch_store -- inside any basic block that holds MFMAs, i.e. the main loops, where every extra
 instruction is paid for (in-order issue).  SGPR spills outside the loops
-(prologue, epilogue, stream-K bookkeeping: 36-57 in the fused kernel, 4 in one GEMM variant) cost a
+(prologue, epilogue, stream-K bookkeeping: 36-57 in the fused kernel, up to 37 in the GEMM's stream-K variants) cost a
 lane move each and are only bounded."""
 import os
 import re
@@ -67,7 +67,7 @@ def _compile_report(src, tmp_path):
 
 def test_gemm_kernel_keeps_four_waves_per_simd(tmp_path):
     k = {n: v for n, v in _compile_report("conv1x1.hip", tmp_path).items() if "conv1x1_bn_kernel" in n}
-    assert len(k) == 4, sorted(k)          # {4, 8 waves} x {plain, stream-K}
+    assert len(k) == 8, sorted(k)          # {4, 8 waves} x {plain, stream-K} x {no residual, residual}
     for name, v in k.items():
         # 8-wave form: 60 KB of LDS -> two workgroups per CU -> 4 waves per SIMD -> 128 VGPRs.
         # 4-wave form: 44 KB -> three workgroups (a fourth does not fit) -> 3 waves per SIMD -> 168.
@@ -79,7 +79,7 @@ def test_gemm_kernel_keeps_four_waves_per_simd(tmp_path):
         # stream-K variants): a few accesses per tile, bounded here; none of it may sit in a
         # block with MFMAs.
         assert v["vgprs"] <= budget and v["occupancy"] >= waves and v["spill"] <= 8, (name, v)
-        assert v["mfma"] >= 56 and v["spill_code_in_mfma_blocks"] == 0 and v["sgpr_spill"] <= 32, (name, v)
+        assert v["mfma"] >= 56 and v["spill_code_in_mfma_blocks"] == 0 and v["sgpr_spill"] <= 40, (name, v)
 
 
 def test_fused_kernel_keeps_two_waves_per_simd(tmp_path):

@@ -52,7 +52,7 @@ N = int(os.environ.get("AB_N", "128"))
 M = N * 196
 rnd = lambda *s: (torch.rand(*s, device=dev) - 0.5)
 only = os.environ.get("AB_ONLY", "")   # "3x3" / "1x1": just those layers
-for (Cin, Kout, relu) in ((512, 128, 1), (128, 512, 0), (1024, 256, 1), (256, 1024, 0), (64, 256, 0), (2048, 512, 1)) if only != "3x3" else ():
+for (Cin, Kout, relu) in ((512, 128, 1), (128, 512, 0), (1024, 256, 1), (256, 1024, 0), (64, 256, 0), (2048, 512, 1)) if only not in ("3x3", "block") else ():
     A, B, b, s, C = rnd(M, Cin), rnd(Cin, Kout), rnd(Kout), rnd(Kout), torch.empty(M, Kout, device=dev)
     fns = [(lambda L=L: L.wino_conv1x1_bn(A.data_ptr(), B.data_ptr(), b.data_ptr(), s.data_ptr(), C.data_ptr(), M, Cin, Kout, relu, st())) for _, L in libs]
     outs = []
@@ -60,7 +60,7 @@ for (Cin, Kout, relu) in ((512, 128, 1), (128, 512, 0), (1024, 256, 1), (256, 10
         C.fill_(float("nan")); assert f() == 0; outs.append(C.clone())
     same = all(torch.equal(o, outs[0]) for o in outs)
     bench(f"1x1 {Cin}->{Kout} N={N}{'' if same else '  (DIFFER)'}", fns)
-if only != "3x3":
+if only not in ("3x3", "block"):
     # the block's last layer: 256 -> 1024 + skip + ReLU, A padded
     Apad, B, b, s, R, C = rnd(N, 16, 16, 256), rnd(256, 1024), rnd(1024), rnd(1024), rnd(M, 1024), torch.empty(M, 1024, device=dev)
     fns = [(lambda L=L: L.wino_conv1x1_bn_ex(Apad.data_ptr(), B.data_ptr(), b.data_ptr(), s.data_ptr(), R.data_ptr(), C.data_ptr(), M, 256, 1024, 1 | 2 | 8, st())) for _, L in libs]
@@ -69,7 +69,23 @@ if only != "3x3":
     A, B, b, s, Cp = rnd(M, 1024), rnd(1024, 256), rnd(256), rnd(256), torch.empty(N, 16, 16, 256, device=dev)
     fns = [(lambda L=L: L.wino_conv1x1_bn_ex(A.data_ptr(), B.data_ptr(), b.data_ptr(), s.data_ptr(), None, Cp.data_ptr(), M, 1024, 256, 1 | 4, st())) for _, L in libs]
     bench("1x1 1024->256 (C padded)", fns)
-for Cc in (128, 256) if only != "1x1" else ():
+if only in ("", "block"):
+    C4, Cm = 1024, 256
+    x, w1, w3 = rnd(M, C4), rnd(C4, Cm), rnd(Cm, C4)
+    w2 = rnd(Cm, Cm, 3, 3); U2 = torch.empty(16 * Cm * Cm, device=dev)
+    libs[0][1].wino_filter_transform_f2(w2.data_ptr(), U2.data_ptr(), Cm, Cm, st())
+    v = [rnd(Cm) for _ in range(4)] + [rnd(C4) for _ in range(2)]
+    outb = torch.empty(M, C4, device=dev)
+    wsb = libs[0][1].wino_residual_block_workspace_bytes(N, Cm)
+    ws = torch.empty(wsb // 4 + 64, device=dev)
+    fns = [(lambda L=L: L.wino_residual_block(x.data_ptr(), w1.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), U2.data_ptr(), v[2].data_ptr(), v[3].data_ptr(),
+                                              w3.data_ptr(), v[4].data_ptr(), v[5].data_ptr(), outb.data_ptr(), N, C4, Cm, ws.data_ptr(), wsb, st())) for _, L in libs]
+    outs = []
+    for f in fns:
+        outb.fill_(float("nan")); assert f() == 0; outs.append(outb.clone())
+    same = all(torch.equal(o, outs[0]) for o in outs)
+    bench(f"bottleneck block 1024/256 N={N}{'' if same else '  (DIFFER)'}", fns, reps=100)
+for Cc in (128, 256) if only not in ("1x1", "block") else ():
     x, w, b, s = rnd(N, 16, 16, Cc), rnd(Cc, Cc, 3, 3), rnd(Cc), rnd(Cc)
     U, out = torch.empty(16 * Cc * Cc, device=dev), torch.empty(N, 16, 16, Cc, device=dev)
     libs[0][1].wino_filter_transform_f2(w.data_ptr(), U.data_ptr(), Cc, Cc, st())

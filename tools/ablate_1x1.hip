@@ -41,13 +41,13 @@ void sweep(const float* A, const float* B, const float* b, const float* s, float
 template <int NW>
 float run_block_tail(const float* Apad, const float* B, const float* b, const float* s, const float* R, float* C, long M, int Cin, int Kout, int reps) {
   using G = Cfg<32, NW>;
-  CK(hipFuncSetAttribute((const void*)(conv1x1_bn_kernel<32, NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void*)(conv1x1_bn_kernel<32, NW, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   const int nMB = (int)((M + BM - 1) / BM);
   const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
   const int flags = WINO_RELU | WINO_A_PADDED | WINO_ADD_RESIDUAL;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  auto launch = [&] { hipLaunchKernelGGL((conv1x1_bn_kernel<32, NW, 0>), dim3(grid), dim3(G::NT), G::LDS_BYTES, 0, Apad, B, b, s, R, C, M, Cin, Kout, flags, nMB, 0L, 0L, 0L, wino::gemm1x1::SkArgs{nullptr, nullptr, nullptr}, wino::gemm1x1::make_padgeo(14, 14)); };
+  auto launch = [&] { hipLaunchKernelGGL((conv1x1_bn_kernel<32, NW, 0, false, true>), dim3(grid), dim3(G::NT), G::LDS_BYTES, 0, Apad, B, b, s, R, C, M, Cin, Kout, flags, nMB, 0L, 0L, 0L, wino::gemm1x1::SkArgs{nullptr, nullptr, nullptr}, wino::gemm1x1::make_padgeo(14, 14)); };
   for (int i = 0; i < 5; i++) launch();
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
