@@ -196,7 +196,7 @@ static int sk_workspace(int dev, hipStream_t s, int G, size_t items, float** sla
 constexpr int SK_MIN_ITERS = 8, SK_ALIGNED_MIN_ITERS = 4;
 // (hand-off refitted after the loop changes of this round: whole items vs the all-tail grid at 128 / 192 /
 //  256 / 384 channels, N = 46..100, solve to 2.7-3.6 iterations; it was 4.8)
-constexpr double SK_EPILOGUE_ITERS = 2.3, SK_HANDOFF_ITERS = 3.2;
+constexpr double SK_EPILOGUE_ITERS = 2.3, SK_HANDOFF_ITERS = 3.2, SK_HANDOFF_ALLTAIL_ITERS = 5.0;
 static double sk_cost(long long items, int nchunks, long long G) {
   const long long ndp = items / G, tail_items = items % G;
   double c = (double)ndp * (nchunks + SK_EPILOGUE_ITERS);
@@ -208,7 +208,13 @@ static double sk_cost(long long items, int nchunks, long long G) {
     // aligned ranges against 27.3-28.1 with 8-iteration unaligned ones.
     const bool aligned = tail_T % G == 0 && per < nchunks && nchunks % per == 0;
     const double segments = aligned ? 1.0 : (double)((per + nchunks - 1) / nchunks) + 1.0;
-    c += (double)per + segments * SK_EPILOGUE_ITERS + SK_HANDOFF_ITERS;
+    // (an all-tail grid whose ranges straddle items gathers everything at the very end of the launch, on every
+    //  workgroup's critical path: re-measured after the ticket rule of round 2 -- 256 channels N = 24 / 32 / 48 / 64
+    //  and 128 channels N = 96 solve to 4.1-6.2 iterations, against 2.7-3.2 for aligned ranges and 1.5-3 behind
+    //  whole-item rounds; with 5.0 the policy takes the aligned halves at 256 channels N = 32 (45.1 against 48.0 us)
+    //  and whole items at N = 64 (72.7 against 75.2) and at 128 channels N = 96 (39.8 against 40.8))
+    const double handoff = (!aligned && ndp == 0) ? SK_HANDOFF_ALLTAIL_ITERS : SK_HANDOFF_ITERS;
+    c += (double)per + segments * SK_EPILOGUE_ITERS + handoff;
   }
   return c;
 }

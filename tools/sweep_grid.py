@@ -30,7 +30,7 @@ bv = torch.rand(256, device=dev)
 out = torch.empty(128, 16, 16, 256, device=dev)
 for _ in range(3000): pkg.conv3x3_bn_relu(x, U, bv, bv, out=out)
 torch.cuda.synchronize()
-for C in (256, 128):
+for C in ([int(a) for a in sys.argv[1:]] or [256, 128]):
     U = pkg.filter_transform_f2(torch.rand(C, C, 3, 3, device=dev) - 0.5)
     bv = torch.rand(C, device=dev)
     for N in (8, 12, 16, 24, 32, 40, 48, 64, 80, 96, 112, 160, 192):
