@@ -215,6 +215,11 @@ static double sk_cost(long long items, int nchunks, long long G) {
     //  and whole items at N = 64 (72.7 against 75.2) and at 128 channels N = 96 (39.8 against 40.8))
     const double handoff = (!aligned && ndp == 0) ? SK_HANDOFF_ALLTAIL_ITERS : SK_HANDOFF_ITERS;
     c += (double)per + segments * SK_EPILOGUE_ITERS + handoff;
+    // (Not modelled: ranges of one or two iterations cut an item into many segments, and whoever gathers it reads
+    //  their slabs one after the other.  192 channels, N = 112 -- 258 items on 256 CUs, a 48-iteration tail, 24
+    //  segments per item -- takes 119.6 us against 107.1 for two even rounds on 129 workgroups; a per-segment term
+    //  that catches this case (0.9-1.0 iterations per segment) mis-prices 128 channels N = 176 and 384 channels
+    //  N = 112, where the same kind of tail costs 0.4 per segment and the even rounds lose 16-17 %.  Left as is.)
   }
   return c;
 }

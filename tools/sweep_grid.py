@@ -33,7 +33,7 @@ torch.cuda.synchronize()
 for C in ([int(a) for a in sys.argv[1:]] or [256, 128]):
     U = pkg.filter_transform_f2(torch.rand(C, C, 3, 3, device=dev) - 0.5)
     bv = torch.rand(C, device=dev)
-    for N in (8, 12, 16, 24, 32, 40, 48, 64, 80, 96, 112, 160, 192):
+    for N in [int(a) for a in os.environ.get("SWEEP_N", "8,12,16,24,32,40,48,64,80,96,112,160,192").split(",")]:
         x = torch.rand(N, 16, 16, C, device=dev) - 0.5
         out = torch.empty(N, 16, 16, C, device=dev)
         fn = lambda: pkg.conv3x3_bn_relu(x, U, bv, bv, out=out)
