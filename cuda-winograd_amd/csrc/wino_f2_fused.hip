@@ -333,16 +333,16 @@ static int conv3x3_prepare(int N, int H, int W, int C, int K, hipStream_t s) {
   return sk_workspace(dev, s, G, items, &slabs, &tickets);
 }
 
-template <bool GEN>
+template <bool GEN, bool TAIL>
 static int launch_fused(const FusedParams& prm, int G, int dev, hipStream_t s) {
   // raise the dynamic-LDS cap (all 160 KB of the CU) once per device
   static std::atomic<unsigned long long> attr_done{0};
   if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
-    WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<0, GEN>),
+    WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<0, GEN, TAIL>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done.fetch_or(1ull << (dev & 63));
   }
-  hipLaunchKernelGGL((wino_f2_fused_kernel<0, GEN>), dim3(G), dim3(NTHREADS), LDS_BYTES, s, prm);
+  hipLaunchKernelGGL((wino_f2_fused_kernel<0, GEN, TAIL>), dim3(G), dim3(NTHREADS), LDS_BYTES, s, prm);
   return launch_status("wino_f2_fused_kernel");
 }
 
@@ -393,8 +393,9 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
   const Geo geo = {H + 2, W + 2, tiles, tiles_x, make_fastdiv(tiles), make_fastdiv(tiles_x)};
   const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
                            geo, bnBias, bnScale, out, slabs, tickets, nullptr};
-  if (!fixed14) return launch_fused<true>(prm, G, dev, s);
-  return launch_fused<false>(prm, G, dev, s);
+  // whole items only (no stream-K tail): the kernel variant without the hand-off in its epilogue
+  if (Tt == 0) return fixed14 ? launch_fused<false, false>(prm, G, dev, s) : launch_fused<true, false>(prm, G, dev, s);
+  return fixed14 ? launch_fused<false, true>(prm, G, dev, s) : launch_fused<true, true>(prm, G, dev, s);
 }
 
 // Diagnostic: the throughput kernel's stamped build (ABLATE = 16: s_memtime / s_memrealtime at the start

@@ -165,7 +165,12 @@ struct FusedParams {
   unsigned long long* dbg;     // diagnostic builds only (ABLATE & (16 | 2048)): where the stamps go
 };
 
-template <int ABLATE, bool GEN = false>
+// TAIL = the launch has a stream-K tail (any partial segment at all).  Launches of whole items only -- every
+// shape whose items fit or divide the grid -- compile the hand-off out of the epilogue: 128 channels N = 128
+// 40.1 -> 39.6 us, 256 channels N = 64 71.7 -> 71.0.  (Tried for the launches WITH a tail in the same step: the
+// gather with two slabs in flight and the accumulators re-zeroed at the end of the epilogue to make room -- no
+// gain at small batches, where an item has up to 8 segments, +0.8..1.2 % at 256 channels N = 96 / 256.)
+template <int ABLATE, bool GEN = false, bool TAIL = true>
 __global__ void __launch_bounds__(NTHREADS, 2)
 wino_f2_fused_kernel(const FusedParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -712,7 +717,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
     // The previous segment's deferred ticket is drawn now.
     int pend_item = __builtin_amdgcn_readfirstlane(pend_vg);
     unsigned pend_old = 0;
-    if (pend_item >= 0) pend_old = draw_ticket(pend_item);   // in flight while A^T m A runs
+    if (TAIL && pend_item >= 0) pend_old = draw_ticket(pend_item);   // in flight while A^T m A runs
     // A^T m A (C/D layout: col = lane&15, row = 4*(lane>>4)+r).  The wave holds point rows i = 2 ph and
     // 2 ph + 1 (local rows 0, 1) for all four column blocks.  Per (tile row r, column block cb):
     //   column transform inside each point row:  c0(i) = m_i0 + m_i1 + m_i2,  c1(i) = m_i1 - m_i2 - m_i3
@@ -774,14 +779,14 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #pragma unroll
       for (int cb = 0; cb < 4; cb++) acc[e][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     phase(1);
-    const bool whole = (seg_kind & 1) != 0;
+    const bool whole = !TAIL || (seg_kind & 1) != 0;
     // up to two items to look at: [0] this segment's, [1] the deferred head segment's
     // (job1 is taken BEFORE this segment may re-arm pend_item with its own deferred ticket -- the second
     //  partial segment of a range that goes on to whole items.  Round 1 tested pend_item != c_item after the
     //  re-arm and lost the drawn item in exactly that case: harmless while the range's neighbour, whose
     //  ticket on that item waits behind a whole item, draws last; an item never finalized when this
     //  workgroup starts late -- a grid beyond the CU count, or CUs shared with another stream's kernel.)
-    int job0 = -1, job1 = pend_item;
+    int job0 = -1, job1 = TAIL ? pend_item : -1;
     pend_item = -1;
     unsigned old0 = 0;
     if (whole) {
@@ -821,7 +826,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
     asm volatile("" : "+v"(pend_vg));
     phase(2);
 #pragma unroll 1
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < (TAIL ? 2 : 1); j++) {
       const int item = j == 0 ? job0 : job1;
       if (item < 0) continue;
       if (!(j == 0 && whole)) {
