@@ -104,7 +104,7 @@ constexpr int lds_wait_count(int e) {
 // `v_add_u32 v, 0, v` per read in the loop -- the dynamic-LDS base is a symbol the optimizer does not
 // fold -- so the fragment address registers carry the base themselves and are used as pointers.)
 __device__ __forceinline__ f32x2 lds_read2(int addr) {
-  return *(const __attribute__((address_space(3))) f32x2*)(unsigned)addr;
+  return *(const __attribute__((address_space(3))) f32x2*)(size_t)(unsigned)addr;   // (size_t: the host pass parses this with 64-bit pointers)
 }
 struct TileCoord {
   int n, ty, tx;
