@@ -890,6 +890,40 @@ def test_random_legal_shapes(pkg, O, torch_dev, knobs):
         assert (got[:, ring, :] == 0).all(), (N, H, W, C, K)
 
 
+def test_random_forced_grids_3x3(pkg, torch_dev, knobs):
+    """Seeded sweep of the 3x3 throughput kernel's hand-off over random shapes AND random forced grids (1 ... 700
+    logical workgroups: fewer than items, more than CUs, whole-item rounds with short and long tails, items cut
+    into many segments), at the reference's 14x14 and at other feature maps: NaN-filled outputs against the direct
+    comparator kernel, every launch twice (bitwise equal), ticket counters at zero after every launch."""
+    torch, dev = torch_dev
+    knobs.set("WINO_3X3_ALGO", "big")
+    rng = np.random.RandomState(777)
+    g = torch.Generator(device="cpu").manual_seed(777)
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
+    for i in range(20):
+        if i % 2 == 0:
+            N, H, W = int(rng.randint(2, 90)), 14, 14
+        else:
+            N, H, W = int(rng.randint(1, 9)), int(rng.randint(3, 30)), int(rng.randint(3, 30))
+        C = 8 * int(rng.randint(1, 24)); K = 64 * int(rng.randint(1, 4))
+        grid = int(rng.randint(1, 700))
+        x, w, sc, bi = mk(N, H + 2, W + 2, C), mk(K, C, 3, 3), mk(K), mk(K)
+        U = pkg.filter_transform_f2(w)
+        want = pkg.conv3x3_direct(x, w, bi, sc)
+        scale = float(want.abs().max())
+        knobs.set("WINO_SK_GRID", str(grid))
+        outs = []
+        for rep in range(2):
+            out = torch.full((N, H + 2, W + 2, K), float("nan"), device=dev)
+            pkg.conv3x3_bn_relu(x, U, bi, sc, out=out)
+            assert pkg.tickets_in_use() == 0, (i, N, H, W, C, K, grid)
+            outs.append(out)
+        knobs.unset("WINO_SK_GRID")
+        assert not bool(torch.isnan(outs[0]).any()), (i, N, H, W, C, K, grid)
+        assert torch.equal(outs[0], outs[1]), (i, N, H, W, C, K, grid)
+        assert float((outs[0] - want).abs().max()) < TIGHT * scale, (i, N, H, W, C, K, grid)
+
+
 def test_residual_block_in_a_graph(pkg, O, torch_dev):
     """The three launches of the bottleneck block captured into one HIP graph: the prepare calls
     allocate every launch's stream-K scratch on the capture stream beforehand (an allocation inside
