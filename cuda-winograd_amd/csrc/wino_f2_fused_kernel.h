@@ -468,12 +468,14 @@ wino_f2_fused_kernel(const FusedParams prm) {
   for (int j = 0; j < 4; j++) issue_u1(0, j);
   // The DMA walker never leaves this workgroup's range: it stops on the last chunk, and the
   // last two iterations of the range fetch that chunk again into stages nobody reads (see body()).
+  if ((ABLATE & 32768) && tid == 0) prm.dbg[(size_t)lg * 8 + 6] = __builtin_amdgcn_s_memrealtime();   // first stage requested
   if (L > 1) dma_advance();
   ring_pass();   // in the shadow of the first pieces' flight
   if (!(ABLATE & 8)) {
     wait_vmem_all();
     __syncthreads();
   }
+  if ((ABLATE & 32768) && tid == 0) prm.dbg[(size_t)lg * 8 + 7] = __builtin_amdgcn_s_memrealtime();   // ... and landed
   if (L > 1) {
 #pragma unroll
     for (int j = 0; j < 4; j++) issue_raw1(1, j);

@@ -101,6 +101,11 @@ int main(int argc, char** argv) {
     printf("%s C=%d N=%d grid=%d: product %.2f us per launch, timeline build %.2f; first entry -> last exit %.2f us (10 ns ticks)\n", argv[0], C, N, wgs, us_prod, us_tl, (tend - t0) * 0.01);
     pr("entry (after the first entry)", entry); pr("first MFMA", first); pr("start of the last epilogue", lastep); pr("exit", exitt);
     pr("entry -> first MFMA", pro); pr("last epilogue -> exit", epi);
+    {
+      std::vector<double> req, land;
+      for (int l = 0; l < wgs; l++) { req.push_back((st[8 * l + 6] - st[8 * l]) * 0.01); land.push_back((st[8 * l + 7] - st[8 * l]) * 0.01); }
+      pr("entry -> first stage requested", req); pr("entry -> first stage landed", land);
+    }
     if (argc > 5) {   // per workgroup, with the shape of its tail range
       const int nTB = (N * 49 + TB - 1) / TB, nch = C / 8;
       const unsigned items = (unsigned)nTB * (K / KB), Tt = (items % wgs) * nch, q = Tt / wgs, rem = Tt % wgs;
