@@ -301,6 +301,38 @@ def test_conv3x3_streamk_with_a_competing_stream(pkg, torch_dev, knobs):
     assert pkg.tickets_in_use() == 0
 
 
+def test_conv1x1_streamk_with_a_competing_stream(pkg, torch_dev, knobs):
+    """The 1x1 kernel's stream-K and split-K forms while a second stream's launches hold CUs (late and
+    non-resident workgroups): results must not move bitwise, counters must return to zero.  Automatic forms at
+    the reference's 1024->256 (stream-K at N = 128, split-K at N = 2) and a forced grid beyond the resident
+    capacity (two 8-wave workgroups per CU)."""
+    torch, dev = torch_dev
+    g = torch.Generator(device="cpu").manual_seed(23)
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
+    xs, ws, vs = mk(64, 16, 16, 128), mk(128, 128, 3, 3), mk(128)
+    Us = pkg.filter_transform_f2(ws)
+    side = torch.cuda.Stream()
+    for (N, Cin, Kout, grid) in [(128, 1024, 256, None), (2, 1024, 256, None), (100, 512, 128, "1024"), (60, 2048, 512, "768")]:
+        A, Bm, b, s = mk(N * 196, Cin), mk(Cin, Kout), mk(Kout), mk(Kout)
+        if grid:
+            knobs.set("WINO_1X1_SK", "1"); knobs.set("WINO_1X1_SK_GRID", grid)
+        try:
+            ref = pkg.conv1x1_bn(A, Bm, b, s, True).clone()
+            want = torch.relu((A.double() @ Bm.double()) * s.double() + b.double())
+            assert float((ref.double() - want).abs().max() / want.abs().max()) < TIGHT, (N, Cin, Kout, grid)
+            torch.cuda.synchronize()
+            for rep in range(15):
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        pkg.conv3x3_bn_relu(xs, Us, vs, vs)
+                for o in [pkg.conv1x1_bn(A, Bm, b, s, True) for _ in range(4)]:
+                    assert torch.equal(o, ref), (N, Cin, Kout, grid, rep)
+            torch.cuda.synchronize()
+            assert pkg.tickets_in_use() == 0, (N, Cin, Kout, grid)
+        finally:
+            knobs.unset("WINO_1X1_SK"); knobs.unset("WINO_1X1_SK_GRID")
+
+
 @pytest.mark.parametrize("N,H,W,C,K", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (5, 8, 12, 16, 64),
                                        (7, 2, 2, 8, 64), (2, 30, 6, 24, 192), (64, 28, 28, 128, 128),
                                        (9, 7, 7, 512, 512), (4, 1, 1, 8, 64), (3, 5, 8, 16, 64), (2, 13, 3, 40, 128)])
