@@ -171,6 +171,7 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   if (ABLATE & 32768) {   // timeline: chip-wide 100 MHz stamps at entry / first MFMA / start of the last epilogue / exit
     if (threadIdx.x == 0) {
       sk.dbg[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+      sk.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime();
       // which CU: HW_REG_HW_ID (cu bits 8-11, se bits 13-15) and HW_REG_XCC_ID
       sk.dbg[(size_t)blockIdx.x * 8 + 4] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
     }
@@ -557,7 +558,10 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   }
   }   // segments
   if (ABLATE & 32768) {
-    if (threadIdx.x == 0) sk.dbg[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+      sk.dbg[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+      sk.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime();
+    }
   }
 }
 

@@ -96,7 +96,9 @@ void timeline(const float* A, const float* B, const float* b, const float* s, fl
     std::sort(v.begin(), v.end());
     printf("  %-34s min %7.2f  p10 %7.2f  median %7.2f  p90 %7.2f  max %7.2f us\n", name, v[0], v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
   };
-  printf("%d->%d NW=%d %s grid=%d: product %.2f us per launch; first entry -> last exit %.2f us\n", Cin, Kout, NW, SKF ? "stream-K" : "plain", grid, us_prod, (tend - t0) * 0.01);
+  double cyc = 0, rt = 0;
+  for (int l = 0; l < grid; l++) { cyc += (double)(st[8 * l + 6] - st[8 * l + 5]); rt += (double)(st[8 * l + 3] - st[8 * l]); }
+  printf("%d->%d NW=%d %s grid=%d: product %.2f us per launch; first entry -> last exit %.2f us; in-kernel clock %.3f GHz\n", Cin, Kout, NW, SKF ? "stream-K" : "plain", grid, us_prod, (tend - t0) * 0.01, cyc / rt * 0.1);
   pr("entry (after the first entry)", entry); pr("entry -> first stage issued", first); pr("start of the last epilogue", lastep); pr("exit", exitt); pr("last epilogue -> exit", epi);
   if (getenv("TL_VERBOSE"))
     for (int l = 0; l < grid; l++) {
