@@ -25,6 +25,9 @@ namespace gemm1x1 {
 #define WINO_1X1_DMA0 4   // first step of a stage (of 14) that issues an LDS-DMA piece of the next one;
                           // tools/ablate_1x1: 0 / 2 / 4 / 6 within 1 % on all four reference shapes, 8 up to +9 %
 #endif
+#ifndef WINO_1X1_SK_PRIO
+#define WINO_1X1_SK_PRIO 0   // experiment, measured slower; tools may build with 1
+#endif
 #ifndef WINO_1X1_PROLOGUE_PRIO
 #define WINO_1X1_PROLOGUE_PRIO 1
 #endif
@@ -224,6 +227,10 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     uend = u + nk;
   }
   const int r16 = lane & 15, h = lane >> 4;
+#if WINO_1X1_SK_PRIO
+  const int sk_range_len = SK ? (int)(uend - u) : 0;
+  int sk_prog = 0;
+#endif
   bool first_seg = true;
   bool first_seg_stamp = true;
   unsigned long long stamp_first = 0;
@@ -364,6 +371,15 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     int it = 0;
 #pragma unroll 1
     for (; it + 2 < len; it += 2) {
+#if WINO_1X1_SK_PRIO
+      if (SK) {   // experiment (tools only): wave priority falls with the progress through the range
+        const int q = 4 * (sk_prog + it) / sk_range_len;
+        if (q == 0) __builtin_amdgcn_s_setprio(3);
+        else if (q == 1) __builtin_amdgcn_s_setprio(2);
+        else if (q == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+#endif
       body(P0{}, std::true_type{}, it);
       body(P1{}, std::true_type{}, it + 1);
     }
@@ -375,6 +391,9 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       body(P0{}, std::false_type{}, it);
     }
   }
+#if WINO_1X1_SK_PRIO
+  sk_prog += len;
+#endif
 
   if (ABLATE & 32768) {
     if (threadIdx.x == 0) {
