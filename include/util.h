@@ -19,7 +19,19 @@
 #ifndef WINO_UTIL_H
 #define WINO_UTIL_H
 
+/* The reference's util.h:9-19 pulls these in for every translation unit that includes it; its own
+ * util.c:1-3 gets printf / malloc / exit / uint64_t from nowhere else, so a reference-side unit may
+ * rely on util.h alone for them.  Same set here, minus the two x86 intrinsics headers (<immintrin.h>,
+ * <xmmintrin.h>), which no caller uses and a non-x86 host does not have. */
+#include <assert.h>
+#include <errno.h>
+#include <float.h>
+#include <inttypes.h>
+#include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {

@@ -111,6 +111,33 @@ def test_reference_file_name_objects_are_source_compatible(tmp_path):
     assert out[0] == out[1] and out[2] == "data/input_14_1_128.bin" and out[3] == "data/weight_one_1024.bin"
 
 
+@pytest.mark.skipif(shutil.which("gcc") is None or shutil.which("g++") is None, reason="no gcc/g++")
+def test_util_h_alone_brings_the_libc_headers_the_reference_hosts_rely_on(tmp_path):
+    """The reference's util.h:9-19 includes <stdio.h> <stdlib.h> <string.h> <math.h> <inttypes.h> <assert.h>
+    <errno.h> <float.h> for everyone (its util.c:1-3 includes nothing else for printf / malloc / exit): a
+    reference-side translation unit that includes ONLY util.h must compile unchanged, as C and as C++."""
+    body = r'''
+#include "util.h"
+int only_util_h(int n) {
+  float* p = (float*)malloc((size_t)n * sizeof(float));
+  uint64_t t = getTimeMicroseconds64();
+  assert(n > 0);
+  if (!p) { printf("malloc: %s\n", strerror(errno)); exit(0); }
+  memset(p, 0, (size_t)n * sizeof(float));
+  p[0] = (float)fabs(-1.5) + FLT_EPSILON;
+  printf("%" PRIu64 " %f\n", t, p[0]);
+  free(p);
+  return 0;
+}
+'''
+    (tmp_path / "u.c").write_text(body)
+    (tmp_path / "u.cpp").write_text(body)
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-I" + INC, "-c", str(tmp_path / "u.c"),
+                           "-o", str(tmp_path / "u_c.o")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + INC, "-c", str(tmp_path / "u.cpp"),
+                           "-o", str(tmp_path / "u_cpp.o")])
+
+
 def test_file_names_are_the_ones_the_generator_writes(gen_mod, tmp_path):
     """Every name object of the four headers is a file this repo's generator (byte-identical to the
     reference's, tests/test_generator.py) actually writes."""
