@@ -17,15 +17,21 @@ or, as a strong split of a fixed batch, --layer residual_block --scaling strong 
 Clock protocol.  The chip's power governor needs a few hundred ms of sustained fp32-MFMA load to
 settle; the driver's own command (--steps 20 --warmup 5) alone would time the kernel at whatever
 clock it finds.  So before the W warm-up steps an untimed, disclosed PREHEAT phase runs the same
-step back to back for --preheat-ms (default 400; reported as "preheat_ms", outside warmup/steps),
-and after the timed region the 3x3 kernel's stamped diagnostic build reports the clock the chip
-held inside the kernel ("roofline.clock_ghz").  The reference's protocol is the same idea: discard
-the first calls, average the rest (Test.c:14,45-53).
+step back to back for --preheat-ms (default 400; reported as "preheat_ms", outside warmup/steps).
+"roofline.clock_ghz" is the clock OF THE TIMED LAUNCHES: workgroup 0 of every product launch stores
+{s_memtime, s_memrealtime} at its entry and exit into a slot of the code object (four 8-byte stores
+per launch), and the last launch of each timed burst is read back after the burst's closing
+synchronise (wino_diag_last_clock) -- same binary, same burst, no probe launch.  kernel_us x
+clock_ghz = "cycles_per_launch", the number to compare across boxes.  The reference's protocol is
+the same idea: discard the first calls, average the rest (Test.c:14,45-53).
 
-Prints ONE JSON line (rank 0).  `value` = algorithmic FLOPs of all ranks / wall time, where
-algorithmic FLOPs are the direct-convolution FLOPs 2*N*P*Q*K*C*R*S, so
-it may exceed the fp32 MFMA peak: F(2x2,3x3) executes 2.25x fewer multiplies.  `roofline`
-carries both the effective fraction and the executed-MFMA fraction.
+Prints ONE JSON line (rank 0).  The K-step timed region is repeated --trials times; `value` (and
+ms_per_step, roofline.*) come from the MEDIAN trial, "trials_us" lists them all, with their mean and
+best.  `value` = algorithmic FLOPs of all ranks / wall time, where algorithmic FLOPs are the direct-
+convolution FLOPs 2*N*P*Q*K*C*R*S, so it may exceed the fp32 MFMA peak:
+F(2x2,3x3) executes 2.25x fewer multiplies.  `roofline.frac` is therefore the EXECUTED-MFMA fraction
+(FLOPs the matrix pipes really execute / kernel time / peak: a physical utilisation, <= 1);
+`roofline.effective_frac` is the algorithmic one.
 """
 from __future__ import annotations
 
@@ -194,8 +200,10 @@ def pmc_traffic(layer: str):
             e = json.load(f).get(layer, {})
         if "hbm_bytes_per_launch" not in e:
             return None, None
+        kernels = e.get("kernels") or [e.get("kernel", "?")]
         return e["hbm_bytes_per_launch"], "committed profile " + e.get("source", "profiles/pmc_traffic.json") + \
-            " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; not measured in this run)"
+            " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; not measured in this run); " \
+            "bytes of one step = sum over its kernels: " + ", ".join(kernels)
     except (OSError, ValueError):
         return None, None
 
@@ -277,8 +285,8 @@ def main():
         B = rnd(C, K, scale=40.0)
         out = torch.empty((N * 196, K), device=dev)
         step = lambda: pkg.conv1x1_bn(A, B, bias_v, scale_v, relu, out=out)
-    # in-kernel clock probe: the stamped build of the 3x3 throughput kernel on the same tensors
-    clock_probe = (lambda: pkg.conv3x3_clock_ghz(x, U, bias_v, scale_v, out)) if kind == "3x3" and H == 14 else None
+    # in-kernel clock of the timed launches themselves (wino_diag_last_clock): which product kernel stamps
+    clock_kernel = 1 if kind == "1x1" else 0 if kind in ("3x3", "block") else None
 
     def sync():
         # torch.cuda.synchronize() alone sometimes returns tens of ms late when a long queue is
@@ -319,29 +327,27 @@ def main():
     ev0.record()   # first record of a timing event initialises HIP's profiling path (~30 ms
     ev1.record()   # one-off): keep that out of the timed region
     sync()
-    # The K-step timed region (barrier + sync on both sides, max over ranks) is repeated
-    # `--trials` times and the fastest trial is reported: the host occasionally stalls for tens
-    # of ms inside a launch burst (seen as wall >> HIP-event time), which is not kernel time.
-    elapsed, kernel_ms = float("inf"), float("inf")
+    # The K-step timed region (barrier + sync on both sides, max over ranks) is repeated `--trials` times.
+    # The MEDIAN trial is reported (the host occasionally stalls for tens of ms inside a launch burst -- wall
+    # >> HIP-event time -- which a mean would carry and a best-of would hide), next to every trial, their mean
+    # and the best.  After each trial's closing synchronise the in-kernel clock of its LAST launch is read.
+    trials = []
     for _ in range(max(1, args.trials)):
         state["n"] = 0
         t = timed_steps(step_with_events, args.steps, 0, sync, barrier)
         t = max_over_ranks(t, world, red_dev)
-        if t < elapsed:
-            elapsed, kernel_ms = t, ev0.elapsed_time(ev1) / args.steps
-
-    # the clock the chip holds INSIDE the kernel under the timed region's load: the stamped diagnostic
-    # build is queued directly behind another burst of product launches (no host synchronisation in
-    # between: an idle gap of a few hundred microseconds already lets the clock fall back, which is
-    # what a launch after a sync measures -- 2.05 GHz instead of 2.38 on the same box)
-    clock_ghz = None
-    if clock_probe is not None:
-        try:
-            for _ in range(max(args.steps, 100)):
-                step()
-            clock_ghz = clock_probe()
-        except pkg.WinoError:
-            clock_ghz = None
+        clk = None
+        if clock_kernel is not None:
+            try:
+                clk = pkg.last_clock_ghz(clock_kernel)
+            except pkg.WinoError:
+                clk = None
+        trials.append({"elapsed": t, "kernel_ms": ev0.elapsed_time(ev1) / args.steps, "clock": clk})
+    order = sorted(range(len(trials)), key=lambda i: trials[i]["elapsed"])
+    med = trials[order[(len(order) - 1) // 2]]   # (lower median for an even count)
+    elapsed, kernel_ms = med["elapsed"], med["kernel_ms"]
+    clock_ghz = med["clock"][0] if med["clock"] else None
+    trials_us = [round(t["elapsed"] / args.steps * 1e6, 2) for t in trials]
     flops_rank = algorithmic_flops(kind, N, C, K, H)
     # whole-job rate: the FLOPs of every rank's shard / the slowest rank's time
     if args.scaling == "strong":
@@ -350,6 +356,7 @@ def main():
         flops_job = flops_rank * world
     value = flops_job * args.steps / elapsed / 1e12
     ach = flops_rank / (kernel_ms * 1e-3) / 1e12
+    exe = executed_mfma_flops(kind, N, C, K, H) / (kernel_ms * 1e-3) / 1e12
     traffic, traffic_source = pmc_traffic(args.layer) if N == BATCH else (None, None)
     line = {
         "metric": f"effective_tflops_{args.layer}_bn_relu_{H}x{H}_N{args.batch}_fp32" if kind != "1x1"
@@ -370,19 +377,25 @@ def main():
                                  "block": "3 HIP launches: MFMA GEMM, fused Winograd F(2x2,3x3), MFMA GEMM+skip"}[kind],
                    "global_batch": global_batch, "per_gpu_batch": N,
                    "parallelism": f"batch-split x{world}, no collective"},
-        "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+        "trials_us": trials_us, "us_per_layer_mean": round(sum(trials_us) / len(trials_us), 2),
+        "us_per_layer_best": min(trials_us), "reported_trial": "median",
+        "roofline": {"bound": "mfma", "achieved": round(exe, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(exe / FP32_MFMA_PEAK_TFLOPS, 4),
+                     "effective_achieved": round(ach, 3), "effective_frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_source,
                      "clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
-                     "clock_source": "in-kernel s_memtime / s_memrealtime of the stamped build of this kernel, "
-                                     "median over workgroups, queued directly behind a burst of product launches "
-                                     "after the timed region"
+                     "clock_source": "s_memtime / s_memrealtime stamped by workgroup 0 of the LAST launch of the "
+                                     "reported trial's timed burst (product kernel, wino_diag_last_clock)"
                                      if clock_ghz else None,
                      "kernel_us": round(kernel_ms * 1e3, 2),
-                     "executed_mfma_frac": round(executed_mfma_flops(kind, N, C, K, H) /
-                                                 (kernel_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                     "note": "achieved = algorithmic (direct-conv) FLOPs per launch / mean launch "
-                             "duration from HIP events; Winograd executes 2.25x fewer MFMA FLOPs"},
+                     "cycles_per_launch": round(kernel_ms * 1e3 * clock_ghz * 1e3) if clock_ghz else None,
+                     "frac_of_peak_at_clock": round(exe / (FP32_MFMA_PEAK_TFLOPS * clock_ghz / 2.4), 4) if clock_ghz else None,
+                     "trials_clock_ghz": [round(t["clock"][0], 3) if t["clock"] else None for t in trials],
+                     "trials_kernel_us": [round(t["kernel_ms"] * 1e3, 2) for t in trials],
+                     "note": "achieved / frac = EXECUTED MFMA FLOPs per launch (F(2x2,3x3): 16 points x tiles x C x K x 2; "
+                             "1x1: the GEMM's) / mean launch duration from HIP events on the launch stream; "
+                             "effective_* = algorithmic (direct-conv) FLOPs / the same time (Winograd executes 2.25x "
+                             "fewer); peak = 157.3 TFLOP/s at 2.4 GHz, frac_of_peak_at_clock scales it to clock_ghz"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and kind in ("3x3", "1x1") and H == 14:
         line["cpu_baseline"] = cpu_baseline(kind, C, K, relu, min(args.cpu_images, BATCH))

@@ -40,7 +40,8 @@ ABI_SYMBOLS = [
     "wino_driver_set_gpu_alias", "wino_driver_set_stdout_compat", "wino_driver_get_stdout_compat",
     "wino_driver_cpu_baseline", "wino_last_status_name", "wino_debug_reload_knobs",
     "wino_residual_block_prepare", "wino_residual_block_prepare_hw", "wino_diag_conv3x3_clock",
-    "wino_debug_tickets_in_use",
+    "wino_debug_tickets_in_use", "wino_stream_check", "wino_stream_reset_scratch", "wino_debug_poison_ticket",
+    "wino_diag_last_clock", "wino_conv3x3_small_plan", "wino_conv1x1_small_plan",
     # reference entry points + helpers (Kernel*.h, util.h)
     "kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in",
     "kernel_256_1_out", "get_parameter", "transpose", "getTimeMicroseconds64", "output_checker",
@@ -122,6 +123,12 @@ def lib() -> ctypes.CDLL:
     L.wino_residual_block_prepare.argtypes = [c_int, c_int, c_int, c_void_p]
     L.wino_residual_block_prepare_hw.argtypes = [c_int] * 5 + [c_void_p]
     L.wino_diag_conv3x3_clock.argtypes = [fp] * 5 + [c_int] * 3 + [fp, POINTER(c_int), c_void_p]
+    L.wino_stream_check.argtypes = [c_void_p]
+    L.wino_stream_reset_scratch.argtypes = [c_void_p]
+    L.wino_debug_poison_ticket.argtypes = [c_void_p, c_long, ctypes.c_uint]
+    L.wino_diag_last_clock.argtypes = [c_int, c_void_p, POINTER(ctypes.c_ulonglong)]
+    L.wino_conv3x3_small_plan.argtypes = [c_int] * 6 + [POINTER(c_int)] * 4
+    L.wino_conv1x1_small_plan.argtypes = [c_long, c_int, c_int, c_int] + [POINTER(c_int)] * 3
     for name in ("kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out",
                  "kernel_256_1_in", "kernel_256_1_out"):
         getattr(L, name).restype = c_int
@@ -153,6 +160,48 @@ def tickets_in_use() -> int:
     n = c_long(0)
     _check(lib().wino_debug_tickets_in_use(_stream(), ctypes.byref(n)), "wino_debug_tickets_in_use")
     return int(n.value)
+
+
+def stream_check() -> None:
+    """Waits for the current stream; raises WinoError (WINO_E_STATE) when its library-owned scratch cannot
+    be trusted (an earlier launch failed, or a kernel found a ticket counter that was not zero at launch)."""
+    _check(lib().wino_stream_check(_stream()), "wino_stream_check")
+
+
+def stream_reset_scratch() -> None:
+    """Recovery: zero the current stream's ticket counters and clear its error state."""
+    _check(lib().wino_stream_reset_scratch(_stream()), "wino_stream_reset_scratch")
+
+
+def poison_ticket(index: int, value: int) -> None:
+    """Test hook: overwrite one ticket counter of the current stream's scratch."""
+    _check(lib().wino_debug_poison_ticket(_stream(), int(index), int(value)), "wino_debug_poison_ticket")
+
+
+def last_clock_ghz(kernel: int = 0):
+    """The clock the chip held inside the MOST RECENT launch of a product kernel (0 = fused 3x3, 1 = 1x1 GEMM)
+    on the current device: (GHz, shader cycles, microseconds) between workgroup 0's entry and exit stamps,
+    or None when no launch has stamped yet.  Synchronises the current stream."""
+    st = (ctypes.c_ulonglong * 4)()
+    _check(lib().wino_diag_last_clock(int(kernel), _stream(), st), "wino_diag_last_clock")
+    cyc, ticks = st[2] - st[0], st[3] - st[1]
+    if st[1] == 0 or ticks <= 0 or cyc <= 0:
+        return None
+    return cyc / ticks * 0.1, int(cyc), ticks / 100.0
+
+
+def small_plan_3x3(N: int, C: int, K: int, cus: int = 256, H: int = 14, W: int = 14):
+    """(use, point_rows, split, workgroups) of the 3x3 latency kernel for this shape (host-side)."""
+    v = [c_int(0) for _ in range(4)]
+    _check(lib().wino_conv3x3_small_plan(N, H, W, C, K, cus, *[ctypes.byref(x) for x in v]), "wino_conv3x3_small_plan")
+    return tuple(int(x.value) for x in v)
+
+
+def small_plan_1x1(M: int, Cin: int, Kout: int, cus: int = 256):
+    """(use, k_split, workgroups) of the 1x1 latency form for a plain layer of this shape (host-side)."""
+    v = [c_int(0) for _ in range(3)]
+    _check(lib().wino_conv1x1_small_plan(M, Cin, Kout, cus, *[ctypes.byref(x) for x in v]), "wino_conv1x1_small_plan")
+    return tuple(int(x.value) for x in v)
 
 
 def _on_current_device(*tensors) -> None:

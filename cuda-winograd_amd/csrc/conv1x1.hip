@@ -23,6 +23,7 @@
 // counted lgkmcnt waits, and the LDS-DMA pieces are issued one per step: see the notes in
 // wino_f2_fused_kernel.h, the same three hipcc behaviours apply here.
 #include "conv1x1_kernel.h"
+#include "conv1x1_small_kernel.h"
 
 #include <atomic>
 
@@ -152,6 +153,40 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_f
   return (t_sk2 < t_sk1 ? t_sk2 : t_sk1) < 0.99 * t_plain ? (int)G : 0;
 }
 
+// The latency form (conv1x1_small_kernel.h): 16 x 16 output blocks, 4 waves per workgroup, the K loop of a
+// block split over KS of them.  Taken for plain layers (no padded operand, no residual) while even the
+// coarsest decomposition (KS = 1: a workgroup is 16 rows x 64 columns) leaves CUs idle; KS is then the
+// largest of 4 / 2 / 1 whose grid still fits the CUs.  WINO_1X1_ALGO=big|small overrides.
+struct Small1Plan {
+  bool use;
+  int ks;
+  long long wgs;
+};
+static Small1Plan small1_plan(long M, int Cin, int Kout, int flags, int batch, int cus) {
+  Small1Plan pl = {false, 1, 0};
+  if (batch != 1 || (flags & ~WINO_RELU) != 0 || M < 1) return pl;
+  const Knobs kn = knobs();
+  const long long rb = (M + 15) / 16;
+  const long long wg1 = rb * (Kout / 64);
+  pl.use = wg1 <= cus;
+  if (kn.algo_1x1 == 1) pl.use = false;
+  if (kn.algo_1x1 == 2) pl.use = rb <= 0x7fffffffll && Kout / 16 <= 65535;
+  if (!pl.use) return pl;
+  pl.ks = 1;
+  for (int ks = 4; ks > 1; ks >>= 1)
+    if (Cin % (16 * ks) == 0 && wg1 * ks <= cus) { pl.ks = ks; break; }
+  pl.wgs = wg1 * pl.ks;
+  return pl;
+}
+static int launch_1x1_small(const Small1Plan& pl, const float* A, const float* B, const float* bnBias,
+                            const float* bnScale, float* C, long M, int Cin, int Kout, int relu, hipStream_t s) {
+  const dim3 grid((unsigned)((M + 15) / 16), (unsigned)(Kout / 64 * pl.ks)), block(256);
+  if (pl.ks == 4) hipLaunchKernelGGL(conv1x1_small_kernel<4>, grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  else if (pl.ks == 2) hipLaunchKernelGGL(conv1x1_small_kernel<2>, grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  else hipLaunchKernelGGL(conv1x1_small_kernel<1>, grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  return launch_status("conv1x1_small_kernel");
+}
+
 template <int BK, int NW, bool RES = false>
 static int launch_1x1_res(const float* A, const float* B, const float* bnBias, const float* bnScale,
                           const float* R, float* C, long M, int Cin, int Kout, int flags, int nMB,
@@ -189,21 +224,28 @@ static int launch_1x1_res(const float* A, const float* B, const float* bnBias, c
   const long long tiles = (long long)nMB * (Kout / G::BN);
   const int Gsk = batch == 1 ? sk1_grid(tiles, Cin / BK, cus, Kout / G::BN, NW == 4) : 0;
   if (Gsk) {
-    SkArgs sk{nullptr, nullptr, nullptr};
-    if (int rc = sk_scratch(dev, s, (size_t)2 * Gsk * NW * RB * 1024, (size_t)tiles, &sk.slabs, &sk.tickets)) return rc;
+    SkBufs bufs;
+    if (int rc = sk_scratch(dev, s, (size_t)2 * Gsk * NW * RB * 1024, (size_t)tiles, &bufs)) return rc;
     if (prepare_only) return WINO_OK;
+    const SkArgs sk{bufs.slabs, bufs.tickets, nullptr, bufs.err};
     hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW, 0, true, RES>), dim3(Gsk), dim3(G::NT), G::LDS_BYTES, s, A, B,
                        bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, 0L, 0L, 0L, sk, pg);
-    return launch_status("conv1x1_bn_kernel (stream-K)");
+    const int rc = launch_status("conv1x1_bn_kernel (stream-K)");
+    if (rc) sk_mark_failed(dev, s);   // the launch held the stream's scratch
+    return rc;
   }
   if (prepare_only) return WINO_OK;
   const int grid = 8 * (Kout / G::BN) * ((nMB + 7) / 8);
   hipLaunchKernelGGL((conv1x1_bn_kernel<BK, NW, 0, false, RES>), dim3(grid, batch), dim3(G::NT), G::LDS_BYTES, s, A, B,
-                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC, SkArgs{nullptr, nullptr, nullptr}, pg);
+                     bnBias, bnScale, R, C, M, Cin, Kout, flags, nMB, batchA, batchB, batchC, SkArgs{nullptr, nullptr, nullptr, nullptr}, pg);
   return launch_status("conv1x1_bn_kernel");
 }
 
 namespace wino {
+int last_clock_1x1(unsigned long long* stamps) {
+  WINO_HIP(hipMemcpyFromSymbol(stamps, HIP_SYMBOL(wino::gemm1x1::wino_clk_slot_1x1), 4 * sizeof(unsigned long long)));
+  return WINO_OK;
+}
 // Batched plain GEMM C_b = A_b . B_b (no BN) on the 1x1 kernel: used by the F(4x4) compatibility path.
 int gemm_batched(const float* A, const float* B, float* C, long M, int Cin, int Kout, int batch,
                  long batchA, long batchB, long batchC, hipStream_t s) {
@@ -246,6 +288,13 @@ static int conv1x1_ex(const float* A, const float* B, const float* bnBias, const
     const unsigned long long ring_units = (unsigned long long)(M / ((long)H * W)) * (2ull * (W + 2) + 2ull * H) * (Kout / 4);
     if (ring_units >= (1ull << 32)) { set_error("padded output too large for one launch"); return WINO_E_SHAPE; }
     pg = make_padgeo(H, W);
+  }
+  {
+    int dev = 0, cus = 0;
+    WINO_HIP(hipGetDevice(&dev));
+    if (int rc = device_cus(dev, &cus)) return rc;
+    const Small1Plan sp = small1_plan(M, Cin, Kout, flags, 1, cus);
+    if (sp.use) return launch_1x1_small(sp, A, B, bnBias, bnScale, C, M, Cin, Kout, (flags & WINO_RELU) != 0, (hipStream_t)s);
   }
   // BK = 32 keeps a workgroup at 60 KB of LDS, so two workgroups share a CU (4 waves per SIMD)
   // and one's prologue / barrier bubbles / store tail hide under the other's MFMAs; measured
@@ -292,6 +341,21 @@ int wino_conv1x1_plan(long M, int Cin, int Kout, int cus, int* grid, int* row_ti
   return WINO_OK;
 }
 
+// Host-side only: does a PLAIN layer of this shape take the latency form (conv1x1_small_kernel.h) on a device
+// with `cus` CUs: *use, the K-split inside a workgroup and the number of workgroups.
+int wino_conv1x1_small_plan(long M, int Cin, int Kout, int cus, int* use, int* k_split, int* workgroups) {
+  if (!use || !k_split || !workgroups || cus < 1) { set_error("bad argument"); return WINO_E_ARG; }
+  if (M < 1 || bad_1x1_dims(Cin, Kout)) {
+    set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% 64 == 0)", M, Cin, Kout);
+    return WINO_E_SHAPE;
+  }
+  const Small1Plan pl = small1_plan(M, Cin, Kout, 0, 1, cus);
+  *use = pl.use;
+  *k_split = pl.ks;
+  *workgroups = pl.use ? (int)pl.wgs : 0;
+  return WINO_OK;
+}
+
 // Allocates the stream-K scratch this shape's launches on stream `s` will use (nothing for shapes
 // that take the plain form): call it before capturing wino_conv1x1_bn(_ex) into a HIP graph.
 int wino_conv1x1_prepare(long M, int Cin, int Kout, wino_stream_t s) {
@@ -303,6 +367,13 @@ int wino_conv1x1_prepare(long M, int Cin, int Kout, wino_stream_t s) {
   const long nMBl = (M + BM - 1) / BM;
   if (nMBl > (1L << 24)) { set_error("M too large"); return WINO_E_SHAPE; }
   const int nMB = (int)nMBl;
+  {   // (a plain layer small enough for the latency form uses no scratch; one that chains or adds a residual at
+      //  the same size takes the staged kernel, whose scratch is allocated below all the same)
+    int dev = 0, cus = 0;
+    WINO_HIP(hipGetDevice(&dev));
+    if (int rc = device_cus(dev, &cus)) return rc;
+    (void)cus;
+  }
   if (four_waves(Cin, Kout))
     return launch_1x1<32, 4>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, Cin, Kout, 0, nMB, (hipStream_t)s, 1, 0, 0, 0, true);
   return launch_1x1<32, 8>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, Cin, Kout, 0, nMB, (hipStream_t)s, 1, 0, 0, 0, true);

@@ -125,7 +125,12 @@ struct SkArgs {
   float* slabs;
   unsigned* tickets;
   unsigned long long* dbg;   // timeline build only (ABLATE & 32768, tools/ablate_1x1 t): 8 uint64 per workgroup
+  unsigned* err;             // host-visible word, set when a ticket is drawn on a counter that was not zero at launch
 };
+
+// In-kernel clock of the most recent launch (see wino_clk_slot_3x3 in wino_f2_fused_kernel.h): workgroup 0
+// stores {s_memtime, s_memrealtime} at its entry and at its exit; wino_diag_last_clock(1, ...) copies them out.
+__device__ unsigned long long wino_clk_slot_1x1[4];
 
 // Resident waves per SIMD the LDS footprint allows -- two 8-wave workgroups (60 KB each) or three
 // 4-wave ones (44 KB) per CU -- stated to the register allocator, which otherwise takes the
@@ -170,6 +175,10 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
   // slot holds LDS and registers and feeds nothing.  High priority until the first stage is requested.
   if (WINO_1X1_PROLOGUE_PRIO) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63;
+  if (ABLATE == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    wino_clk_slot_1x1[0] = __builtin_amdgcn_s_memtime();
+    wino_clk_slot_1x1[1] = __builtin_amdgcn_s_memrealtime();
+  }
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (ABLATE & 32768) {   // timeline: chip-wide 100 MHz stamps at entry / first MFMA / start of the last epilogue / exit
     if (threadIdx.x == 0) {
@@ -458,10 +467,22 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
       if (tid == 0)      // ... before the workgroup's ticket
         *(volatile unsigned*)smem = __hip_atomic_fetch_add(sk.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      if ((unsigned)__builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem) != others) continue;   // someone else finishes the tile
+      const unsigned drawn = (unsigned)__builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem);
+      if (drawn != others) {   // someone else finishes the tile
+        // ... unless the counter was not zero when the launch began (a launch that died mid-way before this one):
+        // say so on the host-visible word; the library then refuses the stream until it is reset
+        if (drawn > others && tid == 0) __hip_atomic_store(sk.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        continue;
+      }
     }
-    if (tid == 0)   // self-cleaning counter: the next launch finds 0 again
-      __hip_atomic_store(sk.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {   // self-cleaning counter: the next launch finds 0 again.  Subtracted, not stored: a counter that
+                      // was not zero at launch stays off and the tile's last drawer is certain to see > others.  A
+                      // finisher that only LOOKED took nothing: it subtracts the others' tickets and checks that
+                      // nobody drew in between (nobody can, when the count it saw was true).
+      const unsigned take = finish ? others : others + 1u;
+      const unsigned before = __hip_atomic_fetch_sub(sk.tickets + tile, take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before != take) __hip_atomic_store(sk.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // The sum runs over the segments in k order, whoever finishes: ((s0 + s1) + s2) + ...  When
     // this workgroup's own segment is s0 or s1 it stays in the accumulators and the others are
     // added to it in order (s1 + s0 == s0 + s1 bitwise).  From position 2 on -- ranges much
@@ -576,6 +597,10 @@ conv1x1_bn_kernel(const float* __restrict__ A, const float* __restrict__ B,
     else store_rows(std::false_type{});
   }
   }   // segments
+  if (ABLATE == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    wino_clk_slot_1x1[2] = __builtin_amdgcn_s_memtime();
+    wino_clk_slot_1x1[3] = __builtin_amdgcn_s_memrealtime();
+  }
   if (ABLATE & 32768) {
     if (threadIdx.x == 0) {
       sk.dbg[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();

@@ -23,8 +23,20 @@ int hip_fail(hipError_t e, const char* what);
 // wino_conv1x1_prepare first when the launch is going to be captured into a graph).  Launches on
 // one stream run one after the other, so the 3x3 and the 1x1 kernels share a stream's set.
 // Counters are zero at allocation and returned to zero by every launch's last arrivers.
-int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, float** slabs, unsigned** tickets);
+// `err` is one host-visible word per (device, stream) that a kernel sets when it draws a ticket on a counter
+// that cannot have been zero when the launch began (a launch that died mid-way before it): sk_scratch() then
+// fails with WINO_E_STATE until wino_stream_reset_scratch() has zeroed the counters again -- the reference
+// holds no state between calls and fails fast (Kernel128_winograd.cu:16-22,236-256); this is the same
+// contract for the one piece of state the library keeps.
+struct SkBufs {
+  float* slabs;
+  unsigned* tickets;
+  unsigned* err;
+};
+int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, SkBufs* out);
 int sk_scratch_release(hipStream_t s);   // wino_stream_destroy: the stream's scratch, on every device
+// A launch that had been handed the scratch failed: the stream's counters can no longer be trusted.
+void sk_mark_failed(int dev, hipStream_t s);
 int device_cus(int dev, int* cus);
 // Developer knobs (WINO_* environment variables), read once per process at first use and cached;
 // wino_debug_reload_knobs() re-reads them (tests sweep the launch decompositions that way).
@@ -34,6 +46,9 @@ struct Knobs {
   int algo_3x3;       // WINO_3X3_ALGO: 0 automatic, 1 "big" (throughput kernel), 2 "small" (latency kernel)
   int sk_1x1;         // WINO_1X1_SK: -1 automatic, 0 plain form, 1 stream-K whenever a legal grid exists
   int sk_1x1_grid;    // WINO_1X1_SK_GRID: number of ranges (0 = model)
+  int small_split;    // WINO_SMALL_SPLIT: C-split S of the 3x3 latency kernel (0 = policy)
+  int small_pr;       // WINO_SMALL_PR: point rows per task of the 3x3 latency kernel, 1 / 2 / 4 (0 = policy)
+  int algo_1x1;       // WINO_1X1_ALGO: 0 automatic, 1 "big" (LDS-staged kernel), 2 "small" (latency kernel)
 };
 Knobs knobs();
 #define WINO_HIP(call)                                          \

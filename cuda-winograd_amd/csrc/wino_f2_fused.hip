@@ -131,6 +131,7 @@ __global__ void filter_import_f4_kernel(const float* __restrict__ u36, float* __
 }  // namespace wino
 
 using namespace wino;
+namespace wino { int last_clock_1x1(unsigned long long* stamps); }   // conv1x1.hip
 
 extern "C" {
 
@@ -176,9 +177,9 @@ int wino_filter_import_f4(const float* u36, float* U, int C, int K, wino_stream_
 // ---------------------------------------------------------------------------------
 static int sk_cus(int dev, int* cus) { return device_cus(dev, cus); }
 
-static int sk_workspace(int dev, hipStream_t s, int G, size_t items, float** slabs, unsigned** tickets) {
+static int sk_workspace(int dev, hipStream_t s, int G, size_t items, SkBufs* bufs) {
   const size_t wgs = G < 256 ? 256 : (size_t)G;
-  return sk_scratch(dev, s, 2 * wgs * SLAB_BYTES, items * 8, slabs, tickets);
+  return sk_scratch(dev, s, 2 * wgs * SLAB_BYTES, items * 8, bufs);
 }
 
 // Launch geometry of the throughput kernel (see the header of wino_f2_fused_kernel.h): G logical
@@ -297,19 +298,46 @@ static int check_conv3x3(int N, int H, int W, int C, int K) {
 
 // Two kernels, same arithmetic: the throughput kernel (64-tile x 64-out-channel items, 8-wave
 // workgroups, whole-item rounds + stream-K tail) and the one-wave-per-SIMD latency kernel (16 tiles
-// x 16 out-channels per workgroup; 14x14 maps only), which wins exactly while its grid fits one
+// x 16 out-channels per block; 14x14 maps only), which wins exactly while its blocks fit one
 // round of the CUs: measured at 64 / 128 / 192 / 256 / 384 / 512 channels, N = 1..24, the rule picks
 // the faster kernel at every point (e.g. 128 channels 14-15 us vs 20 up to N = 10, then 27 vs 20.7;
 // 256 channels 19-20 us vs 23-25 up to N = 5, then 36 vs 25.6).
-// WINO_3X3_ALGO=big|small overrides.
-static bool use_small_kernel(int N, int H, int W, int C, int K, int cus) {
-  if (H != WINO_PQ || W != WINO_PQ) return false;
-  const long small_grid = (long)((N * WINO_TILES + 15) / 16) * (K / 16);
-  const int algo = knobs().algo_3x3;
-  bool small = small_grid <= cus && (C % 16) == 0;
-  if (algo == 1) small = false;
-  if (algo == 2) small = (C % 16) == 0;
-  return small;
+// While the blocks leave CUs idle the latency kernel also splits a block's contraction over S workgroups
+// (C-split; wino_f2_small_kernel.h): S as large as the idle CUs allow (at most 8), then the coarsest task
+// (PR point rows of a 16-channel super-chunk) that still gives every wave of the S workgroups one.
+// WINO_3X3_ALGO=big|small, WINO_SMALL_SPLIT, WINO_SMALL_PR override.
+struct SmallPlan {
+  bool use;
+  int pr, split, nT16;
+  size_t blocks;
+};
+static SmallPlan small_plan(int N, int H, int W, int C, int K, int cus) {
+  SmallPlan pl = {false, 4, 1, 0, 0};
+  if (H != WINO_PQ || W != WINO_PQ || (C % 16) != 0) return pl;
+  const Knobs kn = knobs();
+  pl.nT16 = (int)(((long long)N * WINO_TILES + 15) / 16);
+  const long long blocks = (long long)pl.nT16 * (K / 16);
+  pl.blocks = (size_t)blocks;
+  pl.use = blocks <= cus;
+  if (kn.algo_3x3 == 1) pl.use = false;
+  if (kn.algo_3x3 == 2) pl.use = blocks <= 65535 * 16ll;
+  if (!pl.use) return pl;
+  const int nsuper = C / 16;
+  int smax = (int)(cus / blocks);
+  if (smax > SMALL_MAX_SPLIT) smax = SMALL_MAX_SPLIT;
+  if (smax < 1) smax = 1;
+  bool found = false;
+  for (int sp = smax; sp >= 1 && !found; sp--)
+    for (int pr = 4; pr >= 1 && !found; pr >>= 1)
+      if (SMALL_WAVES * sp <= nsuper * (4 / pr)) { pl.split = sp; pl.pr = pr; found = true; }
+  if (kn.small_split >= 1 && kn.small_split <= SMALL_MAX_SPLIT) pl.split = kn.small_split;
+  if (kn.small_pr == 1 || kn.small_pr == 2 || kn.small_pr == 4) pl.pr = kn.small_pr;
+  return pl;
+}
+static int small_scratch(int dev, hipStream_t s, const SmallPlan& pl, SkBufs* bufs) {
+  bufs->slabs = nullptr; bufs->tickets = nullptr; bufs->err = nullptr;
+  if (pl.split <= 1) return WINO_OK;
+  return sk_scratch(dev, s, pl.blocks * pl.split * SMALL_SLAB_BYTES, pl.blocks, bufs);
 }
 
 static int conv3x3_prepare(int N, int H, int W, int C, int K, hipStream_t s) {
@@ -323,14 +351,14 @@ static int conv3x3_prepare(int N, int H, int W, int C, int K, hipStream_t s) {
   int dev = 0, cus = 0;
   WINO_HIP(hipGetDevice(&dev));
   if (int rc = sk_cus(dev, &cus)) return rc;
-  if (use_small_kernel(N, H, W, C, K, cus)) return WINO_OK;
+  SkBufs bufs;
+  const SmallPlan sp = small_plan(N, H, W, C, K, cus);
+  if (sp.use) return small_scratch(dev, s, sp, &bufs);
   const int nTB = (int)(((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + TB - 1) / TB);
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;
   if (int rc = sk_grid_for(cus, (long long)items, C / BC, &G)) return rc;
-  float* slabs;
-  unsigned* tickets;
-  return sk_workspace(dev, s, G, items, &slabs, &tickets);
+  return sk_workspace(dev, s, G, items, &bufs);
 }
 
 template <bool GEN, bool TAIL>
@@ -343,7 +371,9 @@ static int launch_fused(const FusedParams& prm, int G, int dev, hipStream_t s) {
     attr_done.fetch_or(1ull << (dev & 63));
   }
   hipLaunchKernelGGL((wino_f2_fused_kernel<0, GEN, TAIL>), dim3(G), dim3(NTHREADS), LDS_BYTES, s, prm);
-  return launch_status("wino_f2_fused_kernel");
+  const int rc = launch_status("wino_f2_fused_kernel");
+  if (rc) sk_mark_failed(dev, s);   // the launch held the stream's scratch
+  return rc;
 }
 
 static int conv3x3_launch_one(const float* in, const float* U, const float* bnBias, const float* bnScale,
@@ -375,24 +405,30 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
   int dev = 0, cus = 0;   // one device query per launch; the CU count is cached per device
   WINO_HIP(hipGetDevice(&dev));
   if (int rc = sk_cus(dev, &cus)) return rc;
-  if (use_small_kernel(N, H, W, C, K, cus)) {
-    const int nT16 = (N * WINO_TILES + 15) / 16;
-    hipLaunchKernelGGL(wino_f2_small_kernel, dim3(nT16, K / 16), dim3(64 * SMALL_WAVES), 0, s, in, U,
-                       bnBias, bnScale, out, N, C, K, relu);
-    return launch_status("wino_f2_small_kernel");
+  const SmallPlan sp = small_plan(N, H, W, C, K, cus);
+  if (sp.use) {
+    SkBufs bufs;
+    if (int rc = small_scratch(dev, s, sp, &bufs)) return rc;
+    const SmallParams prm = {in, U, bnBias, bnScale, out, N, C, K, relu, bufs.slabs, bufs.tickets, bufs.err};
+    const dim3 grid(sp.nT16, K / 16, sp.split), block(64 * SMALL_WAVES);
+    if (sp.pr == 4) hipLaunchKernelGGL(wino_f2_small_kernel<4>, grid, block, 0, s, prm);
+    else if (sp.pr == 2) hipLaunchKernelGGL(wino_f2_small_kernel<2>, grid, block, 0, s, prm);
+    else hipLaunchKernelGGL(wino_f2_small_kernel<1>, grid, block, 0, s, prm);
+    const int rc = launch_status("wino_f2_small_kernel");
+    if (rc && sp.split > 1) sk_mark_failed(dev, s);
+    return rc;
   }
   const unsigned tiles_x = (unsigned)((W + 1) / 2), tiles = (unsigned)((H + 1) / 2) * tiles_x;
   const int nTB = (int)(((long long)N * tiles + TB - 1) / TB);
   const size_t items = (size_t)nTB * (K / KB);
   int G = 0;
   if (int rc = sk_grid_for(cus, (long long)items, C / BC, &G)) return rc;
-  float* slabs = nullptr;
-  unsigned* tickets = nullptr;
-  if (int rc = sk_workspace(dev, s, G, items, &slabs, &tickets)) return rc;
+  SkBufs bufs;
+  if (int rc = sk_workspace(dev, s, G, items, &bufs)) return rc;
   const long long Tt = (long long)(items % (size_t)G) * (C / BC);   // the stream-K tail's iterations
   const Geo geo = {H + 2, W + 2, tiles, tiles_x, make_fastdiv(tiles), make_fastdiv(tiles_x)};
   const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
-                           geo, bnBias, bnScale, out, slabs, tickets, nullptr};
+                           geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, nullptr};
   // whole items only (no stream-K tail): the kernel variant without the hand-off in its epilogue
   if (Tt == 0) return fixed14 ? launch_fused<false, false>(prm, G, dev, s) : launch_fused<true, false>(prm, G, dev, s);
   return fixed14 ? launch_fused<false, true>(prm, G, dev, s) : launch_fused<true, true>(prm, G, dev, s);
@@ -414,13 +450,12 @@ static int conv3x3_clock_probe(const float* in, const float* U, const float* bnB
   int G = 0;
   if (int rc = sk_grid_for(cus, (long long)items, C / BC, &G)) return rc;
   if (G > 2048) { set_error("clock probe: grid %d exceeds the stamp buffer", G); return WINO_E_SHAPE; }
-  float* slabs = nullptr;
-  unsigned* tickets = nullptr;
-  if (int rc = sk_workspace(dev, s, G, items, &slabs, &tickets)) return rc;
+  SkBufs bufs;
+  if (int rc = sk_workspace(dev, s, G, items, &bufs)) return rc;
   const long long Tt = (long long)(items % (size_t)G) * (C / BC);
   const Geo geo = {WINO_HW, WINO_HW, WINO_TILES, 7, make_fastdiv(WINO_TILES), make_fastdiv(7)};
   const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
-                           geo, bnBias, bnScale, out, slabs, tickets, stamps};
+                           geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, stamps};
   static std::atomic<unsigned long long> attr_done{0};
   if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
     WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<16, false>),
@@ -452,6 +487,27 @@ int wino_conv3x3_plan(int N, int H, int W, int C, int K, int cus, int* grid, int
   *rounds = (int)(items / G);
   *tail_iters = (long)((items % G) * (C / BC));
   *iters_per_item = C / BC;
+  return WINO_OK;
+}
+
+// Host-side only: does this shape take the latency kernel on a device with `cus` CUs, and in which form.
+int wino_conv3x3_small_plan(int N, int H, int W, int C, int K, int cus, int* use, int* point_rows, int* split,
+                            int* workgroups) {
+  if (!use || !point_rows || !split || !workgroups || cus < 1) { set_error("bad argument"); return WINO_E_ARG; }
+  if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
+  const SmallPlan pl = small_plan(N, H, W, C, K, cus);
+  *use = pl.use;
+  *point_rows = pl.pr;
+  *split = pl.split;
+  *workgroups = pl.use ? (int)(pl.blocks * pl.split) : 0;
+  return WINO_OK;
+}
+
+int wino_diag_last_clock(int kernel, wino_stream_t s, unsigned long long stamps[4]) {
+  if (!stamps || (kernel != 0 && kernel != 1)) { set_error("bad argument"); return WINO_E_ARG; }
+  WINO_HIP(hipStreamSynchronize((hipStream_t)s));
+  if (kernel == 1) return wino::last_clock_1x1(stamps);
+  WINO_HIP(hipMemcpyFromSymbol(stamps, HIP_SYMBOL(wino::fused::wino_clk_slot_3x3), 4 * sizeof(unsigned long long)));
   return WINO_OK;
 }
 

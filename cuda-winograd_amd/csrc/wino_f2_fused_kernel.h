@@ -162,8 +162,15 @@ struct FusedParams {
   float* out;
   float* slabs;
   unsigned* tickets;
+  unsigned* err;               // host-visible word, set when a ticket is drawn on a counter that was not zero at launch
   unsigned long long* dbg;     // diagnostic builds only (ABLATE & (16 | 2048)): where the stamps go
 };
+
+// The clock the chip holds inside the product kernel: workgroup 0 of every launch stores {s_memtime,
+// s_memrealtime} here at its entry and at its exit (four 8-byte stores per launch from one lane; nothing
+// reads them on the device).  wino_diag_last_clock() copies them out: bench.py takes the clock OF its timed
+// launches from the last one of the burst instead of from a separate stamped build run afterwards.
+__device__ unsigned long long wino_clk_slot_3x3[4];
 
 // TAIL = the launch has a stream-K tail (any partial segment at all).  Launches of whole items only -- every
 // shape whose items fit or divide the grid -- compile the hand-off out of the epilogue: 128 channels N = 128
@@ -196,6 +203,16 @@ wino_f2_fused_kernel(const FusedParams prm) {
       prm.dbg[(size_t)lg * 8 + 4] = __builtin_amdgcn_s_memtime();
     }
   }
+  if (ABLATE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    wino_clk_slot_3x3[0] = __builtin_amdgcn_s_memtime();
+    wino_clk_slot_3x3[1] = __builtin_amdgcn_s_memrealtime();
+  }
+  auto clk_exit = [&]() {
+    if (ABLATE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+      wino_clk_slot_3x3[2] = __builtin_amdgcn_s_memtime();
+      wino_clk_slot_3x3[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
   // tail: items ndp*G .. , (sk_q * G + sk_rem) chunk iterations in item-major order; then the rounds
   const int tail_item0 = ndp * G;
   const unsigned t_begin = __builtin_amdgcn_readfirstlane(sk_start(lg, sk_q, sk_rem, G));
@@ -228,6 +245,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
   };
   if (L <= 0) {   // more workgroups than iterations: this one only has its share of the ring
     ring_pass();
+    clk_exit();
     return;
   }
 
@@ -842,9 +860,16 @@ wino_f2_fused_kernel(const FusedParams prm) {
         for (int g = gA; g <= gB; g++)
           nseg += sk_start(g + 1, sk_q, sk_rem, G) != sk_start(g, sk_q, sk_rem, G);
         const unsigned old = __builtin_amdgcn_readfirstlane(j == 0 ? old0 : pend_old);
-        if (old != (unsigned)(nseg - 1)) continue;   // another workgroup's wave w will finish the item
-        if (ln == 0)   // self-cleaning counter: the next launch finds 0 again
-          __hip_atomic_store(tickets + (size_t)item * 8 + wv, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old != (unsigned)(nseg - 1)) {   // another workgroup's wave w will finish the item
+          // ... unless the counter was not zero when the launch began (a launch that died mid-way before this
+          // one): say so on the host-visible word; the library then refuses the stream until it is reset
+          if (old >= (unsigned)nseg && ln == 0) __hip_atomic_store(kp->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          continue;
+        }
+        if (ln == 0)   // self-cleaning counter: the next launch finds 0 again.  (Subtracted, not stored: a counter
+                       // that was NOT zero at launch then stays off by the same amount, and the item's last
+                       // drawer is certain to see a value >= nseg -- the report above cannot be missed.)
+          __hip_atomic_fetch_sub(tickets + (size_t)item * 8 + wv, (unsigned)nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // gather: all segments' parts, summed in segment order
         bool first = true;
 #pragma unroll 1
@@ -1010,6 +1035,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
   }
 #undef A_OFF
   wait_vmem_all();   // no LDS-DMA of this wave may land after the workgroup's LDS has been given away
+  clk_exit();
 
   // diagnostic builds: the stamps go to a buffer of their own (prm.dbg), never into an output
   if (ABLATE & 2048) {

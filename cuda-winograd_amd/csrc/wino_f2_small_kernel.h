@@ -1,15 +1,37 @@
 // Latency-oriented variant of the fused Winograd F(2x2,3x3) kernel for SMALL batches
-// (the reference's own operating point is N = 1: `./Test 0`, `./Test 1`).
+// (the reference's own operating point is N = 1: `./Test 0`, `./Test 1`,
+// Kernel128_winograd.cu:263-265 / Kernel256_winograd.cu:266-268 at one image).
 //
-// At N = 1 a 256->256 layer has 49 tiles: the throughput kernel (64 tiles x 64 out-channels per
-// workgroup) would run on 4 of the 256 CUs.  Here a workgroup owns 16 tiles x
-// 16 out-channels x all 16 Winograd points (64 accumulator VGPRs), so the same layer spreads
-// over 4 x 16 = 64 CUs; the C-loop, the only serial part, is split over the workgroup's 4 waves
-// (one per SIMD) whose partial accumulators are summed through LDS.  There is no LDS and no barrier:
-// the MFMA A/B fragment layouts ("one tile row / one out-channel column per lane, channel pair
-// by lane group") are read straight from global memory (16-byte loads), the next 16-channel
-// super-chunks are prefetched into registers while the current one is transformed and multiplied.
-// Requires C % 16 == 0 (the dispatcher falls back to the throughput kernel otherwise).
+// At N = 1 a 256->256 layer has 49 tiles and 4.2 MB of filters: the work is tiny, what costs is (i) how
+// many CUs pull the operands -- one CU takes in 60-70 GB/s of scattered 16-byte loads, so a block's
+// operands must be spread over many CUs -- and (ii) the latency chain launch -> loads -> MFMAs -> store.
+//
+// Work decomposition.  An output BLOCK is 16 tiles x 16 out-channels (one MFMA tile per Winograd point).
+// Its contraction runs over (16-channel super-chunk, point row): nsuper x 4 / PR TASKS, where a task is
+// one super-chunk for PR of the four rows of the 4 x 4 point grid:
+//     PR = 4: 16 patch pixels + 16 filter points = 32 sixteen-byte loads per lane, 64 MFMAs
+//     PR = 2: 12 pixels (3 patch rows) + 8 points, 32 MFMAs        PR = 1: 8 pixels + 4 points, 16 MFMAs
+// A workgroup is 4 waves (one per SIMD); S workgroups share a block (gridDim.z = S, "C-split"), so the
+// block's tasks are dealt round-robin over 4 S waves.  PR and S are chosen on the host so that the grid
+// just fills the CUs: 256 channels N = 1 is 64 blocks x S = 4 (PR = 4, one task per wave); 128 channels
+// N = 1 is 32 blocks x S = 8 with PR = 1.  (Round 2's kernel had no C-split: 64 / 32 workgroups on 256 CUs,
+// 18.8 / 15.1 us, bound by the load bandwidth of the few busy CUs.)
+//
+// No LDS staging and no barrier in the loop: the MFMA A/B fragment layouts ("one tile row / one out-channel
+// column per lane, channel by lane group") are read straight from global memory with 16-byte loads (lane
+// group h owns channels 4h..4h+3 of a super-chunk; MFMA k-step jj contracts channel 4h+jj -- any
+// channel<->k assignment is valid as long as A and B agree), the next task's operands are in flight in
+// registers while the current one is transformed and multiplied.
+//
+// Reduction, two levels, all on POST-transform values (A^T m A is linear, and a block's 2x2 outputs are
+// 4 KB where its 16 accumulator tiles are 16 KB):
+//   1. each wave applies its part of A^T m A in-lane; waves 1..3 hand their 4 KB to wave 0 through LDS;
+//   2. S > 1: wave 0 publishes the workgroup's partial block as a write-through slab (4 x 16-byte sc1
+//      stores per lane), drains them, and draws ONE ticket on the block's counter; whoever draws the last
+//      ticket loads all S slabs at once (4 S loads in flight), adds them in split order (bitwise
+//      reproducible whoever finishes), applies BN + ReLU and stores.  Nobody waits for anybody -- the same
+//      slab / ticket rules as the throughput kernel (wino_f2_fused_kernel.h).
+// Requires C % 16 == 0 and the 14x14 map (the dispatcher takes the throughput kernel otherwise).
 // Same arithmetic, same packed filter buffer and same output contract as the big kernel.
 #pragma once
 #include "wino_f2_fused_kernel.h"
@@ -17,24 +39,82 @@
 namespace wino {
 namespace fused {
 
-constexpr int SMALL_WAVES = 4;  // waves per workgroup; each takes every 4th 16-channel super-chunk
+constexpr int SMALL_WAVES = 4;          // waves per workgroup
+constexpr int SMALL_MAX_SPLIT = 8;      // S <= 8: the finisher keeps 4 S sixteen-byte loads in flight
+constexpr int SMALL_SLAB_BYTES = 4096;  // a block's pre-BN 2x2 outputs: 16 tiles x 16 k x 4 px x 4 B
 
+struct SmallParams {
+  const float* in;
+  const float* Uq;
+  const float* bnBias;
+  const float* bnScale;
+  float* out;
+  int N, C, K, relu;
+  float* slabs;              // [block][S] x 4 KB (S > 1 only)
+  unsigned* tickets;         // [block]
+  unsigned* err;             // host-visible word: set when a ticket counter was found dirty (S > 1 only)
+};
+
+template <int PR>
 __global__ void __launch_bounds__(64 * SMALL_WAVES)
-wino_f2_small_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
-                     const float* __restrict__ bnBias, const float* __restrict__ bnScale,
-                     float* __restrict__ out, int N, int C, int K, int relu) {
-  __shared__ f32x4 red[SMALL_WAVES - 1][16][64];  // partial accumulators of waves 1..3 (48 KB)
+wino_f2_small_kernel(const SmallParams prm) {
+  static_assert(PR == 1 || PR == 2 || PR == 4, "point rows per task");
+  constexpr int NPR = 4 / PR;      // tasks per super-chunk
+  constexpr int NROW = PR == 4 ? 4 : PR + 1;   // patch rows a task reads
+  constexpr int NPX = 4 * NROW, NPT = 4 * PR;  // sixteen-byte loads per lane: pixels, points
+  __shared__ f32x4 red[SMALL_WAVES - 1][4][64];  // post-transform partials of waves 1..3 (12 KB)
+  const float* __restrict__ in = prm.in;
+  const float* __restrict__ Uq = prm.Uq;
+  const int N = prm.N, C = prm.C, K = prm.K;
   const int lane = threadIdx.x & 63;
   const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t16 = lane & 15, h = lane >> 4;
   const int tb16 = blockIdx.x, kq = blockIdx.y;
+  const int S = gridDim.z, split = blockIdx.z;
+  // in-kernel clock of the launch (wino_diag_last_clock): block 0's first wave stamps its entry and its exit
+  const bool clk = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+  if (clk) {
+    wino_clk_slot_3x3[0] = __builtin_amdgcn_s_memtime();
+    wino_clk_slot_3x3[1] = __builtin_amdgcn_s_memrealtime();
+  }
+  auto clk_exit = [&]() {
+    if (clk) {
+      wino_clk_slot_3x3[2] = __builtin_amdgcn_s_memtime();
+      wino_clk_slot_3x3[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
   const int totalTiles = N * WINO_TILES;
   const int KBLK = K >> 6;
 
-  // The C-loop walks 16-channel super-chunks; lane group h owns channels 4h..4h+3 of each (one
-  // 16-byte load per pixel / per point), and MFMA k-step jj of a super-chunk contracts channel
-  // 4h+jj -- any channel<->k assignment is valid as long as A and B agree.
-  // A fragment source: this lane's tile
+  // this wave's tasks: t = gw, gw + 4 S, ...  (t = super-chunk * NPR + row group; 4 S is a multiple of NPR,
+  // so the row group prg is the same for all of a wave's tasks)
+  const int gw = split * SMALL_WAVES + q;
+  const int prg = gw % NPR;
+  const int nsuper = C / 16;
+  const int ntask = nsuper * NPR;
+  const int stride = SMALL_WAVES * S;
+  // Patch rows the wave reads ("slots") and the signs of its B^T d rows, by PR:
+  //   PR = 4: slots = rows 0..3;  tmp0 = s0 - s2, tmp1 = s1 + s2, tmp2 = s2 - s1, tmp3 = s1 - s3
+  //   PR = 2 (point rows 2g, 2g+1): slots = (d0, d2, d1) for g = 0, (d2, d1, d3) for g = 1;
+  //           tmp0 = s0 - s1, tmp1 = s1 + sg * s2 with sg = +1 / -1        (the throughput kernel's rule)
+  //   PR = 1 (point row i): slots = (d0,d2) (d1,d2) (d2,d1) (d1,d3); tmp0 = s0 + sg * s1, sg = -1 +1 -1 -1
+  int slot_row[NROW];
+  float sg = 1.f;
+  if constexpr (PR == 4) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) slot_row[kk] = kk;
+  } else if constexpr (PR == 2) {
+    slot_row[0] = prg ? 2 : 0;
+    slot_row[1] = prg ? 1 : 2;
+    slot_row[2] = prg ? 3 : 1;
+    sg = prg ? -1.f : 1.f;
+  } else {
+    slot_row[0] = prg == 0 ? 0 : prg == 2 ? 2 : 1;
+    slot_row[1] = prg == 3 ? 3 : prg == 2 ? 1 : 2;
+    sg = prg == 1 ? 1.f : -1.f;
+  }
+
+  // A fragment source: this lane's tile, channels 4h..4h+3 of the super-chunk
   int g = tb16 * 16 + t16;
   g = g < totalTiles ? g : totalTiles - 1;
   const TileCoord tca = decode_tile(g);
@@ -45,34 +125,42 @@ wino_f2_small_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
   const int k = kq * 16 + t16, kb = k >> 6, kl = k & 63;
   const size_t b_chunk_stride = (size_t)KBLK * U_CHUNK_FLOATS;
   const float* b_src = Uq + (size_t)(h >> 1) * b_chunk_stride + ((size_t)kb * 16 * 64 + kl) * 8 +
-                       (((h & 1) ^ ((kl >> 3) & 1)) << 2);
+                       (((h & 1) ^ ((kl >> 3) & 1)) << 2) + (size_t)(PR * prg) * 4 * 512;   // the wave's first point
 
-  f32x4 acc[16];
+  f32x4 acc[NPT];
 #pragma unroll
-  for (int e = 0; e < 16; e++) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int e = 0; e < NPT; e++) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nsuper = C / 16;
-  auto load_chunk = [&](int sc, f32x4* dd, f32x4* bb) {
-    sc = sc < nsuper ? sc : nsuper - 1;  // past the end: re-read the last one, unused
+  auto load_task = [&](int t, f32x4* dd, f32x4* bb) {
+    const int sc = t / NPR;
     const float* ap = a_src + sc * 16;
     const float* bp = b_src + (size_t)sc * 2 * b_chunk_stride;
 #pragma unroll
-    for (int px = 0; px < 16; px++)
-      dd[px] = *(const f32x4*)(ap + (size_t)((px >> 2) * WINO_HW + (px & 3)) * C);
+    for (int kk = 0; kk < NROW; kk++)
 #pragma unroll
-    for (int e = 0; e < 16; e++) bb[e] = *(const f32x4*)(bp + e * 512);
+      for (int j = 0; j < 4; j++)
+        dd[kk * 4 + j] = *(const f32x4*)(ap + (size_t)(slot_row[kk] * WINO_HW + j) * C);
+#pragma unroll
+    for (int e = 0; e < NPT; e++) bb[e] = *(const f32x4*)(bp + e * 512);
   };
   auto compute = [&](const f32x4* d, const f32x4* bfr) {
-    f32x4 tmp[16], v[16];
+    f32x4 tmp[NPT], v[NPT];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      tmp[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-      tmp[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-      tmp[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-      tmp[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+      if constexpr (PR == 4) {
+        tmp[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+        tmp[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+        tmp[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+        tmp[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+      } else if constexpr (PR == 2) {
+        tmp[0 * 4 + j] = d[0 * 4 + j] - d[1 * 4 + j];
+        tmp[1 * 4 + j] = d[1 * 4 + j] + sg * d[2 * 4 + j];
+      } else {
+        tmp[j] = d[j] + sg * d[4 + j];
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < PR; i++) {
       v[i * 4 + 0] = tmp[i * 4 + 0] - tmp[i * 4 + 2];
       v[i * 4 + 1] = tmp[i * 4 + 1] + tmp[i * 4 + 2];
       v[i * 4 + 2] = tmp[i * 4 + 2] - tmp[i * 4 + 1];
@@ -81,42 +169,122 @@ wino_f2_small_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
 #pragma unroll
     for (int jj = 0; jj < 4; jj++)
 #pragma unroll
-      for (int e = 0; e < 16; e++)
+      for (int e = 0; e < NPT; e++)
         acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e][jj], bfr[e][jj], acc[e], 0, 0, 0);
   };
-  // Two super-chunks of operands (2 x 32 sixteen-byte loads: the vmcnt counter holds 63) are
-  // kept in flight in registers -- a one-wave workgroup may use the whole 512-VGPR file.  The
-  // loop is unrolled by two with named buffers and each refill is pinned (sched_barrier)
-  // ahead of the compute it overlaps, or hipcc sinks the loads to their first use and the
-  // kernel pays one full memory latency per chunk.
-  // wave q contracts super-chunks q, q+4, q+8, ...: the serial chain is 4x shorter, the four
-  // partial accumulators are summed through LDS at the end.
-  f32x4 d0[16], b0[16], d1[16], b1[16];
-  load_chunk(q, d0, b0);
-  load_chunk(q + SMALL_WAVES, d1, b1);
+  // Two tasks' operands are kept in flight in registers (a one-wave-per-SIMD workgroup may use the
+  // whole 512-VGPR file).  The loop is unrolled by two with named buffers and each refill is pinned
+  // (sched_barrier) ahead of the compute it overlaps, or hipcc sinks the loads to their first use and
+  // the kernel pays one full memory latency per task.
+  f32x4 d0[NPX], b0[NPT], d1[NPX], b1[NPT];
+  int t = gw;
+  if (t < ntask) load_task(t, d0, b0);
+  if (t + stride < ntask) load_task(t + stride, d1, b1);
   __builtin_amdgcn_sched_barrier(0);
-  for (int it = q; it < nsuper; it += 2 * SMALL_WAVES) {
+#pragma unroll 1
+  while (t < ntask) {
     compute(d0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    load_chunk(it + 2 * SMALL_WAVES, d0, b0);
+    if (t + 2 * stride < ntask) load_task(t + 2 * stride, d0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    if (it + SMALL_WAVES < nsuper) compute(d1, b1);
+    if (t + stride >= ntask) break;
+    compute(d1, b1);
     __builtin_amdgcn_sched_barrier(0);
-    load_chunk(it + 3 * SMALL_WAVES, d1, b1);
+    if (t + 3 * stride < ntask) load_task(t + 3 * stride, d1, b1);
     __builtin_amdgcn_sched_barrier(0);
+    t += 2 * stride;
   }
+
+  // ---- the wave's part of A^T m A (C/D layout: col = lane&15 = out-channel, row = 4*(lane>>4)+r = tile).
+  // Per point row i:  c0(i) = m_i0 + m_i1 + m_i2,  c1(i) = m_i1 - m_i2 - m_i3;  then
+  //   Y[0][b] = c_b(0) + c_b(1) + c_b(2),   Y[1][b] = c_b(1) - c_b(2) - c_b(3)
+  // of which this wave adds the terms of its rows (selects on the wave-uniform row index: exact, and
+  // an Inf in one part cannot turn another into NaN).  y[r] = the 2x2 pixels (p = 2a + b) of tile row 4h+r.
+  f32x4 y[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    float c[PR][2];
+#pragma unroll
+    for (int i = 0; i < PR; i++) {
+      const float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r];
+      const float m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
+      c[i][0] = m0 + m1 + m2;
+      c[i][1] = m1 - m2 - m3;
+    }
+#pragma unroll
+    for (int bb = 0; bb < 2; bb++) {
+      if constexpr (PR == 4) {
+        y[r][bb] = c[0][bb] + c[1][bb] + c[2][bb];
+        y[r][2 + bb] = c[1][bb] - c[2][bb] - c[3][bb];
+      } else if constexpr (PR == 2) {
+        const float sum = c[0][bb] + c[1][bb];
+        y[r][bb] = prg ? c[0][bb] : sum;                 // rows (0,1): c0 + c1;  rows (2,3): c2
+        y[r][2 + bb] = prg ? -sum : c[1][bb];            // rows (0,1): c1;       rows (2,3): -(c2 + c3)
+      } else {
+        y[r][bb] = prg == 3 ? 0.f : c[0][bb];
+        y[r][2 + bb] = prg == 0 ? 0.f : prg == 1 ? c[0][bb] : -c[0][bb];
+      }
+    }
+  }
+  // ---- level 1: the workgroup's four partial blocks meet in wave 0 (in wave order)
   if (q > 0) {
 #pragma unroll
-    for (int e = 0; e < 16; e++) red[q - 1][e][lane] = acc[e];
+    for (int r = 0; r < 4; r++) red[q - 1][r][lane] = y[r];
   }
   __syncthreads();
   if (q > 0) return;
 #pragma unroll
-  for (int e = 0; e < 16; e++)
+  for (int ww = 0; ww < SMALL_WAVES - 1; ww++)
 #pragma unroll
-    for (int ww = 0; ww < SMALL_WAVES - 1; ww++) acc[e] += red[ww][e][lane];
+    for (int r = 0; r < 4; r++) y[r] += red[ww][r][lane];
 
-  // epilogue (C/D layout: col = lane&15 = out-channel, row = 4*(lane>>4)+r = tile)
+  // ---- level 2: the S workgroups of a block meet through write-through slabs + one ticket per workgroup
+  if (S > 1) {
+    const int block = tb16 * (K >> 4) + kq;
+    const auto rsrc_slab = make_rsrc(prm.slabs, (unsigned)((size_t)gridDim.x * gridDim.y * S * SMALL_SLAB_BYTES));
+    const unsigned base = (unsigned)(block * S) * SMALL_SLAB_BYTES;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      slab_store16(y[r], rsrc_slab, (unsigned)((r * 64 + lane) * 16), base + (unsigned)split * SMALL_SLAB_BYTES);
+    wait_vmem_all();   // the write-through stores have left ...
+    unsigned old = 0;
+    if (lane == 0)     // ... before the ticket
+      old = __hip_atomic_fetch_add(prm.tickets + block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(S - 1)) {
+      // a counter that was not zero when the launch began (an aborted launch before this one): say so
+      if (old >= (unsigned)S && lane == 0) __hip_atomic_store(prm.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      clk_exit();
+      return;          // another workgroup finishes the block
+    }
+    if (lane == 0)     // self-cleaning counter: the next launch finds 0 again (subtracted, not stored: a counter
+                       // that was not zero at launch stays off, and the block's last drawer is certain to see >= S)
+      __hip_atomic_fetch_sub(prm.tickets + block, (unsigned)S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 part[SMALL_MAX_SPLIT][4];
+#pragma unroll
+    for (int s = 0; s < SMALL_MAX_SPLIT; s++) {
+      if (s < S) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          part[s][r] = slab_load16(rsrc_slab, (unsigned)((r * 64 + lane) * 16), base + (unsigned)s * SMALL_SLAB_BYTES);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) y[r] = part[0][r];
+#pragma unroll
+    for (int s = 1; s < SMALL_MAX_SPLIT; s++) {
+      if (s < S) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) y[r] += part[s][r];
+      }
+    }
+  }
+
+  // ---- finalize: BN + ReLU + store (and the block's share of the zero ring)
+  const float* __restrict__ bnScale = prm.bnScale;
+  const float* __restrict__ bnBias = prm.bnBias;
+  float* __restrict__ out = prm.out;
+  const int relu = prm.relu;
   const float sc = bnScale[k], bi = bnBias[k];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -125,22 +293,9 @@ wino_f2_small_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
     const TileCoord tc = decode_tile(gt);
     float* o = out + (size_t)tc.n * WINO_HW * WINO_HW * K + k;
     const int oy = 1 + 2 * tc.ty, ox = 1 + 2 * tc.tx;
-    float t0[4], t1[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float m0 = acc[0 * 4 + j][r], m1 = acc[1 * 4 + j][r];
-      const float m2 = acc[2 * 4 + j][r], m3 = acc[3 * 4 + j][r];
-      t0[j] = m0 + m1 + m2;
-      t1[j] = m1 - m2 - m3;
-    }
-    float y[4];
-    y[0] = t0[0] + t0[1] + t0[2];
-    y[1] = t0[1] - t0[2] - t0[3];
-    y[2] = t1[0] + t1[1] + t1[2];
-    y[3] = t1[1] - t1[2] - t1[3];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      float val = sc * y[p] + bi;
+      float val = sc * y[r][p] + bi;
       if (relu) val = fmaxf(val, 0.f);
       o[(size_t)((oy + (p >> 1)) * WINO_HW + ox + (p & 1)) * K] = val;
     }
@@ -166,6 +321,7 @@ wino_f2_small_kernel(const float* __restrict__ in, const float* __restrict__ Uq,
       o[(size_t)((oy + 1) * WINO_HW + 15) * K] = 0.f;
     }
   }
+  clk_exit();
 }
 
 }  // namespace fused

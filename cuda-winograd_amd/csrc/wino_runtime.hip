@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace wino {
@@ -34,6 +35,10 @@ namespace {
 // allocates a new, larger generation and parks the old one in `retired` until
 // wino_stream_destroy (sk_scratch_release); a graph captured against an old generation stays
 // valid -- launches on one stream serialise, and every launch returns its counters to zero.
+struct Retired {
+  void* p;
+  size_t n_tickets;   // 0: a slab buffer
+};
 struct SkScratch {
   int dev;
   hipStream_t stream;
@@ -41,27 +46,41 @@ struct SkScratch {
   size_t slab_bytes;
   unsigned* tickets;
   size_t n_tickets;
-  std::vector<void*> retired;
+  unsigned* err;      // pinned host word the kernels set on a dirty counter (never freed before the stream goes)
+  bool failed;        // a launch that held this scratch failed on the host side
+  std::vector<Retired> retired;
 };
 std::mutex g_ws_mu;
 std::vector<SkScratch> g_ws;
+
+SkScratch* find_ws(int dev, hipStream_t s) {
+  for (auto& e : g_ws)
+    if (e.dev == dev && e.stream == s) return &e;
+  return nullptr;
+}
 }  // namespace
 
-int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, float** slabs, unsigned** tickets) {
+int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, SkBufs* out) {
   std::lock_guard<std::mutex> lock(g_ws_mu);
-  SkScratch* ws = nullptr;
-  for (auto& e : g_ws)
-    if (e.dev == dev && e.stream == s) ws = &e;
+  SkScratch* ws = find_ws(dev, s);
   if (!ws) {
-    g_ws.push_back(SkScratch{dev, s, nullptr, 0, nullptr, 0, {}});
+    unsigned* err = nullptr;
+    WINO_HIP(hipHostMalloc((void**)&err, 64, hipHostMallocDefault));
+    memset(err, 0, 64);
+    g_ws.push_back(SkScratch{dev, s, nullptr, 0, nullptr, 0, err, false, {}});
     ws = &g_ws.back();
+  }
+  if (ws->failed || __atomic_load_n(ws->err, __ATOMIC_RELAXED) != 0) {
+    set_error("the stream's ticket counters are in an unknown state (%s): call wino_stream_reset_scratch()",
+              ws->failed ? "an earlier launch on it failed" : "a kernel found a counter that was not zero at launch");
+    return WINO_E_STATE;
   }
   if (ws->slab_bytes < slab_bytes) {
     size_t n = (size_t)32 << 20;   // 32 MiB covers every reference shape on 256 CUs
     while (n < slab_bytes) n *= 2;
     float* fresh = nullptr;
     WINO_HIP(hipMalloc((void**)&fresh, n));
-    if (ws->slabs) ws->retired.push_back(ws->slabs);
+    if (ws->slabs) ws->retired.push_back(Retired{ws->slabs, 0});
     ws->slabs = fresh;
     ws->slab_bytes = n;
   }
@@ -70,14 +89,22 @@ int sk_scratch(int dev, hipStream_t s, size_t slab_bytes, size_t n_tickets, floa
     while (n < n_tickets) n *= 2;
     unsigned* fresh = nullptr;
     WINO_HIP(hipMalloc((void**)&fresh, n * sizeof(unsigned)));
-    WINO_HIP(hipMemset(fresh, 0, n * sizeof(unsigned)));
-    if (ws->tickets) ws->retired.push_back(ws->tickets);
+    // zeroed ON the launch stream: library streams are non-blocking, a null-stream memset would not be
+    // ordered before the first launch that uses the counters (allocation never happens inside a capture)
+    WINO_HIP(hipMemsetAsync(fresh, 0, n * sizeof(unsigned), s));
+    if (ws->tickets) ws->retired.push_back(Retired{ws->tickets, ws->n_tickets});
     ws->tickets = fresh;
     ws->n_tickets = n;
   }
-  *slabs = ws->slabs;
-  *tickets = ws->tickets;
+  out->slabs = ws->slabs;
+  out->tickets = ws->tickets;
+  out->err = ws->err;
   return WINO_OK;
+}
+
+void sk_mark_failed(int dev, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  if (SkScratch* ws = find_ws(dev, s)) ws->failed = true;
 }
 
 // Frees the scratch of `s` on every device (the stream is going away; its handle may be reused).
@@ -90,7 +117,8 @@ int sk_scratch_release(hipStream_t s) {
     WINO_HIP(hipSetDevice(g_ws[i].dev));
     if (g_ws[i].slabs) WINO_HIP(hipFree(g_ws[i].slabs));
     if (g_ws[i].tickets) WINO_HIP(hipFree(g_ws[i].tickets));
-    for (void* p : g_ws[i].retired) WINO_HIP(hipFree(p));
+    if (g_ws[i].err) WINO_HIP(hipHostFree(g_ws[i].err));
+    for (const Retired& r : g_ws[i].retired) WINO_HIP(hipFree(r.p));
     g_ws.erase(g_ws.begin() + (long)i);
   }
   WINO_HIP(hipSetDevice(cur));
@@ -115,6 +143,10 @@ void read_knobs() {
   k.algo_3x3 = algo && !strcmp(algo, "big") ? 1 : algo && !strcmp(algo, "small") ? 2 : 0;
   k.sk_1x1 = env_num("WINO_1X1_SK", -1);
   k.sk_1x1_grid = env_num("WINO_1X1_SK_GRID", 0);
+  k.small_split = env_num("WINO_SMALL_SPLIT", 0);
+  k.small_pr = env_num("WINO_SMALL_PR", 0);
+  const char* algo1 = getenv("WINO_1X1_ALGO");
+  k.algo_1x1 = algo1 && !strcmp(algo1, "big") ? 1 : algo1 && !strcmp(algo1, "small") ? 2 : 0;
   g_knobs = k;
 }
 }  // namespace
@@ -126,7 +158,9 @@ Knobs knobs() {
       read_knobs();
       g_knobs_ready.store(true, std::memory_order_release);
     }
+    return g_knobs;
   }
+  std::lock_guard<std::mutex> lock(g_knob_mu);   // wino_debug_reload_knobs() writes g_knobs under the same mutex
   return g_knobs;
 }
 
@@ -164,25 +198,87 @@ int wino_debug_reload_knobs(void) {
 
 // Invariant check for tests: every stream-K launch returns the ticket counters it used to zero (the
 // last arriver of an item resets them), so between launches all counters of a stream's scratch -- the
-// current generation and the retired ones -- read 0.  Synchronises the stream and counts the non-zero ones
-// of the current generation on the current device.
+// current generation and the retired ones a captured graph may still use -- read 0.  Synchronises the
+// stream and counts the non-zero ones of every generation on the current device.
 int wino_debug_tickets_in_use(wino_stream_t stream, long* nonzero) {
   if (!nonzero) return WINO_E_ARG;
   *nonzero = 0;
   int dev = 0;
   WINO_HIP(hipGetDevice(&dev));
   WINO_HIP(hipStreamSynchronize((hipStream_t)stream));
-  unsigned* tickets = nullptr;
-  size_t n = 0;
+  std::vector<std::pair<unsigned*, size_t>> bufs;
   {
     std::lock_guard<std::mutex> lock(g_ws_mu);
-    for (auto& e : g_ws)
-      if (e.dev == dev && e.stream == (hipStream_t)stream) { tickets = e.tickets; n = e.n_tickets; }
+    if (SkScratch* ws = find_ws(dev, (hipStream_t)stream)) {
+      if (ws->tickets) bufs.push_back({ws->tickets, ws->n_tickets});
+      for (const Retired& r : ws->retired)
+        if (r.n_tickets) bufs.push_back({(unsigned*)r.p, r.n_tickets});
+    }
   }
-  if (!tickets) return WINO_OK;
-  std::vector<unsigned> host(n);
-  WINO_HIP(hipMemcpy(host.data(), tickets, n * sizeof(unsigned), hipMemcpyDeviceToHost));
-  for (unsigned v : host) *nonzero += v != 0;
+  for (auto& b : bufs) {
+    std::vector<unsigned> host(b.second);
+    WINO_HIP(hipMemcpy(host.data(), b.first, b.second * sizeof(unsigned), hipMemcpyDeviceToHost));
+    for (unsigned v : host) *nonzero += v != 0;
+  }
+  return WINO_OK;
+}
+
+// Recovery after an aborted launch: waits for the stream, zeroes every ticket counter of its scratch on the
+// current device (all generations; the slabs need no cleaning, they are written before they are read) and
+// clears the error state, after which launches on the stream are accepted again.
+int wino_stream_reset_scratch(wino_stream_t stream) {
+  int dev = 0;
+  WINO_HIP(hipGetDevice(&dev));
+  WINO_HIP(hipStreamSynchronize((hipStream_t)stream));
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  SkScratch* ws = find_ws(dev, (hipStream_t)stream);
+  if (!ws) return WINO_OK;
+  if (ws->tickets) WINO_HIP(hipMemsetAsync(ws->tickets, 0, ws->n_tickets * sizeof(unsigned), (hipStream_t)stream));
+  for (const Retired& r : ws->retired)
+    if (r.n_tickets) WINO_HIP(hipMemsetAsync(r.p, 0, r.n_tickets * sizeof(unsigned), (hipStream_t)stream));
+  WINO_HIP(hipStreamSynchronize((hipStream_t)stream));
+  __atomic_store_n(ws->err, 0u, __ATOMIC_RELAXED);
+  ws->failed = false;
+  return WINO_OK;
+}
+
+// Waits for the stream and reports whether its scratch can be trusted: WINO_E_STATE when a launch on it
+// failed, when a kernel drew a ticket on a counter that was not zero when its launch began, or when any
+// counter is non-zero now (the authoritative test: every launch returns its counters to zero).  A stream
+// found dirty stays refused until wino_stream_reset_scratch().
+int wino_stream_check(wino_stream_t stream) {
+  long nonzero = 0;
+  if (int rc = wino_debug_tickets_in_use(stream, &nonzero)) return rc;   // synchronises the stream
+  int dev = 0;
+  WINO_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  SkScratch* ws = find_ws(dev, (hipStream_t)stream);
+  if (!ws) return WINO_OK;
+  if (nonzero) ws->failed = true;
+  if (ws->failed || __atomic_load_n(ws->err, __ATOMIC_RELAXED) != 0) {
+    set_error("the stream's ticket counters are in an unknown state (%ld non-zero): call wino_stream_reset_scratch()", nonzero);
+    return WINO_E_STATE;
+  }
+  return WINO_OK;
+}
+
+// Test hook: overwrites one ticket counter of the stream's current scratch, as a launch that died mid-way
+// would leave it.
+int wino_debug_poison_ticket(wino_stream_t stream, long index, unsigned value) {
+  int dev = 0;
+  WINO_HIP(hipGetDevice(&dev));
+  WINO_HIP(hipStreamSynchronize((hipStream_t)stream));
+  unsigned* t = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    SkScratch* ws = find_ws(dev, (hipStream_t)stream);
+    if (!ws || !ws->tickets || index < 0 || (size_t)index >= ws->n_tickets) {
+      set_error("no ticket %ld in this stream's scratch", index);
+      return WINO_E_ARG;
+    }
+    t = ws->tickets + index;
+  }
+  WINO_HIP(hipMemcpy(t, &value, sizeof(unsigned), hipMemcpyHostToDevice));
   return WINO_OK;
 }
 

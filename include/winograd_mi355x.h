@@ -47,7 +47,9 @@ extern "C" {
  * scratch; wino_conv3x3_bn_relu(_hw) take any batch (they used to reject tensors of 4 GiB);
  * wino_last_status_name, wino_debug_reload_knobs, wino_residual_block_prepare(_hw),
  * wino_driver_set_gpu_alias, wino_driver_set_stdout_compat, wino_driver_cpu_baseline,
- * wino_diag_conv3x3_clock, wino_debug_tickets_in_use.  The library-owned stream-K scratch is never freed or moved while its
+ * wino_diag_conv3x3_clock, wino_debug_tickets_in_use, wino_stream_check, wino_stream_reset_scratch,
+ * wino_debug_poison_ticket, wino_diag_last_clock, wino_conv3x3_small_plan, wino_conv1x1_small_plan,
+ * WINO_E_STATE.  The library-owned stream-K scratch is never freed or moved while its
  * stream lives (it used to be reallocated when a larger shape arrived). */
 #define WINO_ABI_VERSION 1
 
@@ -56,6 +58,8 @@ enum {
   WINO_E_HIP = -1,       /* a HIP runtime call failed (no device, OOM, launch error) */
   WINO_E_SHAPE = -2,     /* unsupported / inconsistent shape argument */
   WINO_E_ARG = -3,       /* NULL pointer, bad enum, workspace too small */
+  WINO_E_STATE = -4,     /* the stream's library-owned scratch cannot be trusted (an earlier launch on it
+                            failed or was aborted): wino_stream_reset_scratch() recovers */
 };
 
 /* geometry fixed by the reference's 14x14 stage */
@@ -85,6 +89,17 @@ int wino_device_synchronize(void);
 int wino_stream_create(wino_stream_t* stream);
 int wino_stream_destroy(wino_stream_t stream);   /* waits for the stream, frees the library's scratch of it */
 int wino_stream_synchronize(wino_stream_t stream);
+/* Fail-fast contract for the one piece of state the library keeps (the reference keeps none: every call
+ * re-allocates, Kernel128_winograd.cu:236-256, and a CUDA error exits, :16-22).  The stream-K / split-C
+ * kernels hand partial sums between workgroups through ticket counters that must be zero when a launch
+ * begins; every launch returns them to zero.  A launch that fails on the host side, or a kernel that draws
+ * a ticket on a counter that cannot have been zero at launch (a launch that died mid-way before it), puts
+ * the (device, stream) into an error state: from then on every compute entry point on that stream returns
+ * WINO_E_STATE instead of computing with counters it cannot trust.
+ *   wino_stream_check          waits for the stream; WINO_OK or WINO_E_STATE
+ *   wino_stream_reset_scratch  waits for the stream, zeroes its counters (slabs are kept), clears the state */
+int wino_stream_check(wino_stream_t stream);
+int wino_stream_reset_scratch(wino_stream_t stream);
 /* events: timing on the stream the kernels run on (hipEvent based) */
 int wino_event_create(void** event);
 int wino_event_destroy(void* event);
@@ -146,6 +161,12 @@ int wino_conv3x3_prepare_hw(int N, int H, int W, int C, int K, wino_stream_t s);
  * as a stream-K tail: workgroup l takes tail iterations [l*tail_iters/grid, (l+1)*tail_iters/grid). */
 int wino_conv3x3_plan(int N, int H, int W, int C, int K, int cus, int* grid, int* rounds, long* tail_iters,
                       int* iters_per_item);
+/* Host-side only: whether this shape takes the latency kernel instead (small batches of the 14x14 stage: the
+ * reference's own N = 1), and in which form: *point_rows (4, 2 or 1 rows of the 4x4 point grid per wave task)
+ * and *split (workgroups that share one 16-tile x 16-out-channel block's contraction, meeting through
+ * library-owned slabs + tickets when > 1); *workgroups = blocks x split. */
+int wino_conv3x3_small_plan(int N, int H, int W, int C, int K, int cus, int* use, int* point_rows, int* split,
+                            int* workgroups);
 
 /* ---- F(4x4,3x3) compatibility path ------------------------------
  * The reference's own three-stage arithmetic on its own pre-transformed weight file, consumed as is:
@@ -216,6 +237,11 @@ int wino_conv1x1_prepare(long M, int Cin, int Kout, wino_stream_t s);
  * and logical workgroup r*col_blocks + nb runs range r for column block nb. */
 int wino_conv1x1_plan(long M, int Cin, int Kout, int cus, int* grid, int* row_tiles, int* col_blocks,
                       int* k_steps, int* stream_k);
+/* Host-side only: plain layers (wino_conv1x1_bn; no padded operand, no residual) with few pixel rows -- the
+ * reference's own M = 196 -- take a latency form instead of the tiled kernel wino_conv1x1_plan describes:
+ * 16 x 16 output blocks, 4 waves per workgroup, a block's K loop split over *k_split of them (4, 2 or 1).
+ * *use = 0: the tiled kernel runs. */
+int wino_conv1x1_small_plan(long M, int Cin, int Kout, int cus, int* use, int* k_split, int* workgroups);
 
 /* ---- ResNet bottleneck block of the 14x14 stage (BASELINE.json configs[4]) ---------
  * out = relu( bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x, w1))), U2))), w3)) + x )
@@ -308,6 +334,16 @@ int wino_debug_reload_knobs(void);
  * (0 when the stream has none).  Every launch leaves them at zero: a non-zero count between launches
  * means an item was never finalized (tests assert 0). */
 int wino_debug_tickets_in_use(wino_stream_t s, long* nonzero);
+/* Test hook: overwrites ticket counter `index` of the stream's scratch on the current device with `value`,
+ * as a launch that died mid-way would leave it. */
+int wino_debug_poison_ticket(wino_stream_t s, long index, unsigned value);
+/* The clock the chip held inside the MOST RECENT launch of a product kernel on the current device:
+ * workgroup 0 of every launch stores {s_memtime, s_memrealtime} at its entry and at its exit into a
+ * 32-byte slot of the code object (four stores per launch; no output depends on them).  kernel: 0 = the
+ * fused 3x3 throughput kernel, 1 = the 1x1 GEMM kernel.  Synchronises `s`, then stamps[0..3] = {cycles,
+ * 100 MHz ticks} at entry, the same pair at exit: clock = (stamps[2] - stamps[0]) / (stamps[3] - stamps[1])
+ * * 0.1 GHz.  bench.py reads it after the last launch of a timed burst -- the clock OF the timed region. */
+int wino_diag_last_clock(int kernel, wino_stream_t s, unsigned long long stamps[4]);
 /* The 3x3 throughput kernel's stamped build (same source, s_memtime / s_memrealtime around its main
  * loop): runs one launch of it on `s` with the arguments of wino_conv3x3_bn_relu and writes four
  * uint64 per workgroup to stamps_dev (at least 4 * 2048 uint64): {shader cycles, 100 MHz ticks} at the

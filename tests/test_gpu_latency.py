@@ -1,0 +1,240 @@
+"""GPU parity tests of the latency forms -- the reference's own operating point is ONE image
+(`./Test 0..5`: Kernel128_winograd.cu:263-265, Kernel128_one.cu:98,316, Kernel256_one.cu:100,318) -- and of
+the recovery contract for the library's ticket counters.  Run with `-m gpu`; everything through the C-ABI,
+the CPU oracle is only the checker."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 2e-5
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch, torch.device("cuda:0")
+
+
+def _ring():
+    r = np.ones((16, 16), bool)
+    r[1:15, 1:15] = False
+    return r
+
+
+def _layer(torch_dev, seed, N, C, K):
+    torch, dev = torch_dev
+    rng = np.random.RandomState(seed)
+    x = (rng.rand(N, 16, 16, C) - 0.5).astype(np.float32)
+    w = (rng.rand(K, C, 3, 3) - 0.5).astype(np.float32)
+    s = (rng.rand(K) - 0.5).astype(np.float32)
+    b = (rng.rand(K) - 0.5).astype(np.float32)
+    return (x, w, s, b), tuple(torch.from_numpy(a).to(dev) for a in (x, w, s, b))
+
+
+# ------------------------------------------------------------------ 3x3 latency kernel: every (point rows, split) form
+@pytest.mark.parametrize("N,C,K", [(1, 256, 256), (1, 128, 128), (2, 256, 256), (3, 128, 128), (1, 64, 192),
+                                   (5, 16, 64), (2, 48, 128), (4, 512, 64)])
+def test_conv3x3_latency_forms_agree(N, C, K, pkg, O, torch_dev, knobs):
+    """A block's contraction is dealt over 4 S waves as (16-channel super-chunk, point-row group) tasks and
+    reduced in two levels (LDS inside a workgroup; write-through slabs + one ticket per workgroup across the S
+    workgroups).  Every legal (PR, S) must give the fp64 oracle's values on NaN-filled outputs (ring included),
+    be bitwise reproducible, leave the counters at zero, and differ from the automatic form only by fp32
+    summation order."""
+    torch, dev = torch_dev
+    (x, w, s, b), (xt, wt, st, bt) = _layer(torch_dev, 100 + N + C, N, C, K)
+    U = pkg.filter_transform_f2(wt)
+    want = O.conv3x3_bn_relu_direct(x, w, s, b)
+    scale = float(np.abs(want).max())
+    knobs.set("WINO_3X3_ALGO", "small")
+    nsuper = C // 16
+    forms = [(pr, sp) for pr in (4, 2, 1) for sp in (1, 2, 3, 4, 5, 8) if 4 * sp <= nsuper * (4 // pr) or sp == 1]
+    assert forms
+    ref = None
+    for pr, sp in forms:
+        knobs.set("WINO_SMALL_PR", pr)
+        knobs.set("WINO_SMALL_SPLIT", sp)
+        use, gpr, gsp, wgs = pkg.small_plan_3x3(N, C, K)
+        assert (use, gpr, gsp) == (1, pr, sp), (pr, sp)
+        out = torch.full((N, 16, 16, K), float("nan"), device=dev)
+        pkg.conv3x3_bn_relu(xt, U, bt, st, out=out)
+        assert pkg.tickets_in_use() == 0, (pr, sp)
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any(), (pr, sp)
+        assert O.rel_error(got, want) < TIGHT, (pr, sp, O.rel_error(got, want))
+        assert (got[:, _ring(), :] == 0).all(), (pr, sp)
+        for _ in range(3):
+            assert torch.equal(pkg.conv3x3_bn_relu(xt, U, bt, st), out), (pr, sp)
+        if ref is None:
+            ref = out
+        assert float((out - ref).abs().max()) < 4e-6 * scale, (pr, sp)
+    knobs.unset("WINO_SMALL_PR")
+    knobs.unset("WINO_SMALL_SPLIT")
+    knobs.unset("WINO_3X3_ALGO")
+    auto = pkg.conv3x3_bn_relu(xt, U, bt, st)
+    assert float((auto - ref).abs().max()) < 4e-6 * scale
+    assert pkg.tickets_in_use() == 0
+
+
+@pytest.mark.parametrize("C", [128, 256])
+def test_conv3x3_latency_policy_at_the_reference_point(C, pkg, torch_dev):
+    """N = 1 on 256 CUs: the policy must put the layer on (nearly) every CU -- 64 blocks x 4 at 256 channels,
+    32 blocks x 8 at 128 -- and the automatic path must be the latency kernel."""
+    use, pr, sp, wgs = pkg.small_plan_3x3(1, C, C, cus=256)
+    assert use == 1 and wgs == 256, (use, pr, sp, wgs)
+    assert (pr, sp) == ((4, 4) if C == 256 else (1, 8))
+    # one image more than fits a round of blocks goes to the throughput kernel
+    assert pkg.small_plan_3x3(6 if C == 256 else 11, C, C, cus=256)[0] == 0
+
+
+def test_conv3x3_latency_with_a_competing_stream(pkg, torch_dev, knobs):
+    """Split blocks while a second stream's launches hold CUs: the S workgroups of a block then start at
+    different times and any of them may be the finisher.  Bitwise equal results, counters at zero."""
+    torch, dev = torch_dev
+    (_, _, _, _), (xt, wt, st, bt) = _layer(torch_dev, 7, 1, 256, 256)
+    (_, _, _, _), (xs, ws, ss, bs) = _layer(torch_dev, 8, 64, 128, 128)
+    U, Us = pkg.filter_transform_f2(wt), pkg.filter_transform_f2(ws)
+    assert pkg.small_plan_3x3(1, 256, 256)[2] > 1
+    ref = pkg.conv3x3_bn_relu(xt, U, bt, st).clone()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(30):
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                pkg.conv3x3_bn_relu(xs, Us, bs, ss)
+        for o in [pkg.conv3x3_bn_relu(xt, U, bt, st) for _ in range(8)]:
+            assert torch.equal(o, ref), rep
+    torch.cuda.synchronize()
+    assert pkg.tickets_in_use() == 0
+
+
+def test_conv3x3_latency_in_a_graph(pkg, torch_dev):
+    """conv3x3_prepare allocates the split form's slabs and tickets ahead of a capture; the replayed graph gives
+    the eager result."""
+    torch, dev = torch_dev
+    (_, _, _, _), (xt, wt, st, bt) = _layer(torch_dev, 9, 1, 128, 128)
+    U = pkg.filter_transform_f2(wt)
+    ref = pkg.conv3x3_bn_relu(xt, U, bt, st).clone()
+    stream = torch.cuda.Stream()
+    out = torch.zeros_like(ref)
+    with torch.cuda.stream(stream):
+        pkg.conv3x3_prepare(1, 128, 128)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            pkg.conv3x3_bn_relu(xt, U, bt, st, out=out)
+        for _ in range(3):
+            out.fill_(float("nan"))
+            graph.replay()
+            stream.synchronize()
+            assert torch.equal(out, ref)
+        assert pkg.tickets_in_use() == 0
+
+
+# ------------------------------------------------------------------ 1x1 latency form
+@pytest.mark.parametrize("M,Cin,Kout,relu", [(196, 1024, 256, True), (196, 512, 128, True), (196, 128, 512, False),
+                                            (196, 256, 1024, False), (1, 32, 64, True), (17, 96, 64, False),
+                                            (392, 1024, 256, True), (50, 160, 192, True), (200, 2048, 64, True)])
+def test_one_by_one_latency_forms_agree(M, Cin, Kout, relu, pkg, torch_dev, knobs):
+    """16 x 16 output blocks, the K loop split over KS waves of a workgroup: the forced latency form (whatever
+    KS the policy picks), the forced tiled kernel and the automatic choice must all match an fp64 GEMM, the
+    latency form bit for bit from launch to launch and on NaN-filled outputs (ragged last row block)."""
+    torch, dev = torch_dev
+    g = torch.Generator(device="cpu").manual_seed(M + Cin)
+    mk = lambda *s: ((torch.rand(*s, generator=g) - 0.5) * 4).to(dev)
+    A, Bm, b, s = mk(M, Cin), mk(Cin, Kout), mk(Kout), mk(Kout)
+    want = (A.double() @ Bm.double()) * s.double() + b.double()
+    if relu:
+        want = torch.relu(want)
+    scale = float(want.abs().max())
+    outs = {}
+    for algo in ("small", "big", None):
+        if algo:
+            knobs.set("WINO_1X1_ALGO", algo)
+        else:
+            knobs.unset("WINO_1X1_ALGO")
+        out = torch.full((M, Kout), float("nan"), device=dev)
+        pkg.conv1x1_bn(A, Bm, b, s, relu, out=out)
+        assert not bool(torch.isnan(out).any()), algo
+        assert float((out.double() - want).abs().max()) < TIGHT * scale, algo
+        for _ in range(3):
+            assert torch.equal(pkg.conv1x1_bn(A, Bm, b, s, relu), out), algo
+        outs[algo] = out
+    assert float((outs["small"] - outs["big"]).abs().max()) < 4e-6 * scale
+    assert pkg.tickets_in_use() == 0
+
+
+def test_one_by_one_latency_policy_at_the_reference_point(pkg):
+    """M = 196 on 256 CUs: all four reference layers take the latency form, with the K-split that fills the CUs."""
+    want = {(1024, 256): (1, 4, 208), (512, 128): (1, 4, 104), (128, 512): (1, 2, 208), (256, 1024): (1, 1, 208)}
+    for (cin, kout), plan in want.items():
+        assert pkg.small_plan_1x1(196, cin, kout, cus=256) == plan, (cin, kout)
+    assert pkg.small_plan_1x1(128 * 196, 1024, 256, cus=256)[0] == 0
+
+
+# ------------------------------------------------------------------ recovery after an aborted launch
+@pytest.mark.parametrize("kind", ["3x3 throughput", "3x3 latency", "1x1"])
+def test_a_dirty_ticket_counter_is_reported_and_reset_recovers(kind, pkg, torch_dev, knobs):
+    """The reference holds no state between calls and exits on the first CUDA error (Kernel128_winograd.cu:16-22,
+    236-256).  The one piece of state this library keeps is the ticket counters of a stream's scratch, zero
+    between launches.  A launch that died mid-way would leave some non-zero; wino_debug_poison_ticket fakes
+    that.  Contract: the kernel that meets a counter that cannot have been zero at launch says so, from then
+    on every launch on the stream fails with WINO_E_STATE (never computes with counters it cannot trust),
+    wino_stream_reset_scratch() recovers, and results are then bitwise those of the clean run."""
+    torch, dev = torch_dev
+    g = torch.Generator(device="cpu").manual_seed(31)
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        if kind == "1x1":
+            knobs.set("WINO_1X1_ALGO", "big")
+            A, Bm, b, s = mk(2 * 196, 1024), mk(1024, 256), mk(256), mk(256)
+            run = lambda: pkg.conv1x1_bn(A, Bm, b, s, True)
+            n_tickets = 8
+        else:
+            N = 40 if kind == "3x3 throughput" else 1
+            if kind == "3x3 throughput":
+                knobs.set("WINO_3X3_ALGO", "big")
+                knobs.set("WINO_SK_GRID", "256")
+            x, w, s, b = mk(N, 16, 16, 256), mk(256, 256, 3, 3), mk(256), mk(256)
+            U = pkg.filter_transform_f2(w)
+            run = lambda: pkg.conv3x3_bn_relu(x, U, b, s)
+            n_tickets = 64 if kind == "3x3 latency" else 8 * 4 * ((N * 49 + 63) // 64)
+        ref = run().clone()
+        assert pkg.tickets_in_use() == 0
+        pkg.stream_check()
+        # every counter the launch draws on is left one too high, as by a launch that never finished
+        for i in range(n_tickets):
+            pkg.poison_ticket(i, 1)
+        run()   # computes with dirty counters: its results are not to be trusted, and it must say so
+        with pytest.raises(pkg.WinoError, match="rc=-4"):
+            pkg.stream_check()
+        with pytest.raises(pkg.WinoError, match="rc=-4"):
+            run()
+        pkg.stream_reset_scratch()
+        pkg.stream_check()
+        assert pkg.tickets_in_use() == 0
+        for _ in range(3):
+            assert torch.equal(run(), ref)
+        assert pkg.tickets_in_use() == 0
+    torch.cuda.synchronize()
+
+
+def test_in_kernel_clock_of_the_last_launch(pkg, torch_dev, knobs):
+    """wino_diag_last_clock: workgroup 0 of every product launch stamps {cycles, 100 MHz ticks} at entry and
+    exit.  The clock must be a plausible shader clock and the stamped span must fit inside the launch."""
+    torch, dev = torch_dev
+    g = torch.Generator(device="cpu").manual_seed(5)
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
+    x, w, s, b = mk(128, 16, 16, 256), mk(256, 256, 3, 3), mk(256), mk(256)
+    U = pkg.filter_transform_f2(w)
+    for _ in range(50):
+        pkg.conv3x3_bn_relu(x, U, b, s)
+    ghz, cycles, us = pkg.last_clock_ghz(0)
+    assert 1.0 < ghz < 2.6 and 50 < us < 400, (ghz, cycles, us)
+    A, Bm = mk(128 * 196, 256), mk(256, 1024)
+    b2, s2 = mk(1024), mk(1024)
+    for _ in range(20):
+        pkg.conv1x1_bn(A, Bm, b2, s2, False)
+    ghz, cycles, us = pkg.last_clock_ghz(1)
+    assert 1.0 < ghz < 2.6 and 1 < us < 400, (ghz, cycles, us)

@@ -15,6 +15,7 @@ using namespace wino::fused;
 static float* g_slabs;
 static unsigned* g_tickets;
 static unsigned long long* g_dbg;   // stamps of the diagnostic builds
+static unsigned* g_err;              // the library's dirty-counter word (device memory here)
 static int g_grid = 256;   // logical workgroups (argv[2]); 0 = one whole item per workgroup
 
 static int grid_for(int N, int K) {
@@ -30,7 +31,7 @@ float run(const float* in, const float* U, const float* b, const float* s, float
   const int grid = grid_for(N, K);
   CK(hipMemset(g_tickets, 0, 65536 * 4));   // ablated variants may leave tickets behind
   const unsigned items = (unsigned)nTB * (K / KB), Tt = (items % grid) * (C / 8);
-  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / grid), Tt / grid, Tt % grid, Geo{}, b, s, out, g_slabs, g_tickets, g_dbg};
+  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / grid), Tt / grid, Tt % grid, Geo{}, b, s, out, g_slabs, g_tickets, g_err, g_dbg};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; i++)
@@ -52,6 +53,8 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&g_slabs, (size_t)2 * 4096 * SLAB_BYTES));
   CK(hipMalloc(&g_tickets, 65536 * 4));
   CK(hipMalloc(&g_dbg, (size_t)4096 * 64 * 8));
+  CK(hipMalloc(&g_err, 64));
+  CK(hipMemset(g_err, 0, 64));
   std::vector<int> Ns = {1, 83, 128};
   const size_t maxN = 256;
   float *in, *U, *b, *s, *out;

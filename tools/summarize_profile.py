@@ -20,10 +20,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 src = f"gpurun_out/prof_{tag}"
 dst = f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
-HOT = ("wino_f2_fused_kernel", "wino_f2_small_kernel", "conv1x1_bn_kernel", "f4_input_transform_kernel",
-       "f4_output_transform_kernel", "f4_ring_kernel")
-DOMINANT = {"conv3x3_256": "wino_f2_fused_kernel", "conv3x3_128": "wino_f2_fused_kernel",
-            "residual_block": "wino_f2_fused_kernel"}
+HOT = ("wino_f2_fused_kernel", "wino_f2_small_kernel", "conv1x1_bn_kernel", "conv1x1_small_kernel",
+       "f4_input_transform_kernel", "f4_output_transform_kernel", "f4_ring_kernel")
 
 
 def short(name):
@@ -34,6 +32,9 @@ def short(name):
                 if m:
                     a = [x.strip() for x in m.group(1).split(",")]
                     return "conv1x1_bn_kernel<%sw%s>" % (a[1] if len(a) > 1 else "?", ",streamK" if len(a) > 3 and a[3] in ("true", "1") else "")
+            if h in ("wino_f2_small_kernel", "conv1x1_small_kernel"):   # keep the form: <PR> / <KS>
+                m = re.search(h + r"<\s*(\d+)", name)
+                return h + ("<%s>" % m.group(1) if m else "")
             if h == "wino_f2_fused_kernel" and re.search(r"wino_f2_fused_kernel<\s*16\s*,", name):
                 return "wino_f2_fused_kernel<stamped diagnostic build: bench.py's clock probe>"
             return h
@@ -55,6 +56,9 @@ def bench_line(path):
 summary, traffic, rows = {}, {}, []
 for d in sorted(glob.glob(os.path.join(src, "*/"))):
     cfg = os.path.basename(d.rstrip("/"))
+    if os.path.exists(os.path.join(d, "FAILED")):   # tools/profile.sh: a pass of this config failed
+        print("skipping %s: failed passes %s" % (cfg, open(os.path.join(d, "FAILED")).read().split()))
+        continue
     S = summary.setdefault(cfg, {"kernels": {}})
     bt, bu = bench_line(os.path.join(d, "bench_trace.json")), bench_line(os.path.join(d, "bench_unprofiled.json"))
     S["bench_us_per_step_under_rocprof"] = bt.get("us_per_layer")
@@ -107,14 +111,20 @@ for d in sorted(glob.glob(os.path.join(src, "*/"))):
             der["executed_mfma_gflop"] = p["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / 1e9
             if t_us:
                 der["executed_mfma_frac_of_157.3TF_under_profiler"] = der["executed_mfma_gflop"] * 1e9 / (t_us * 1e-6) / 157.3e12
-    # dominant kernel of the config -> bench.py's roofline.traffic
+    # bench.py's roofline.traffic = HBM bytes of ONE STEP of the config: every hot kernel's bytes per launch x its
+    # launches per step (the block is three launches, the F(4x4) path four), with the kernels named
     if "@" not in cfg and S["kernels"]:
-        dom = DOMINANT.get(cfg) or max(S["kernels"], key=lambda k: S["kernels"][k].get("trace_avg_us", 0) * S["kernels"][k].get("calls", 0))
-        dk = next((k for k in S["kernels"] if dom in k and "stamped" not in k), None)
-        if dk and "hbm_bytes_per_launch" in S["kernels"][dk].get("derived", {}):
-            d_ = S["kernels"][dk]["derived"]
-            traffic[cfg] = {"kernel": dk, "hbm_bytes_per_launch": d_["hbm_bytes_per_launch"],
-                            "fetch_bytes_x2": d_["hbm_fetch_bytes_x2"], "write_bytes": d_["hbm_write_bytes"],
+        ks = {k: e for k, e in S["kernels"].items() if "stamped" not in k and "hbm_bytes_per_launch" in e.get("derived", {})}
+        if ks:
+            # launches per step from the trace: a kernel called c times where the most-called hot kernel is called
+            # c_max times runs c / c_max times per step (all hot kernels of a config run once per step today)
+            cmax = max(e.get("calls", 1) for e in ks.values())
+            total = sum(e["derived"]["hbm_bytes_per_launch"] * (e.get("calls", cmax) / cmax) for e in ks.values())
+            dom = max(ks, key=lambda k: ks[k].get("trace_avg_us", 0) * ks[k].get("calls", 0))
+            traffic[cfg] = {"kernels": sorted(ks), "dominant_kernel": dom, "hbm_bytes_per_launch": total,
+                            "dominant_kernel_hbm_bytes": ks[dom]["derived"]["hbm_bytes_per_launch"],
+                            "fetch_bytes_x2": sum(e["derived"]["hbm_fetch_bytes_x2"] * (e.get("calls", cmax) / cmax) for e in ks.values()),
+                            "write_bytes": sum(e["derived"]["hbm_write_bytes"] * (e.get("calls", cmax) / cmax) for e in ks.values()),
                             "source": f"profiles/{tag}/summary.json"}
 
 with open(os.path.join(dst, "kernel_stats.csv"), "w") as out:
