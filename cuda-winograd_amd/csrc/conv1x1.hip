@@ -97,9 +97,14 @@ constexpr long long SK1_MAX_GRID = 16384;   // 2 * G slabs of <= 56 KB must stay
 struct Sk1Model { double a_plain, t_plain, e_tile, a_sk1, t_sk1, a_sk2, t_sk2; };
 constexpr Sk1Model SK1_MODEL_8W = {2.7, 1.555, 1.75, 12.0, 1.60, 13.0, 1.558};
 constexpr Sk1Model SK1_MODEL_4W = {3.8, 0.778, 0.7, 9.5, 0.89, 11.0, 0.816};
-static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_form) {
+static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_form, double* t_pred = nullptr) {
   const Knobs kn = knobs();
   const int force = kn.sk_1x1;
+  {   // the plain form's predicted time: what stands when no stream-K / split-K grid is taken
+    const Sk1Model& m0 = four_wave_form ? SK1_MODEL_4W : SK1_MODEL_8W;
+    const long long rounds0 = cus > 0 ? (tiles + cus - 1) / cus : 1;
+    if (t_pred) *t_pred = m0.a_plain + (double)rounds0 * (m0.t_plain * nk + m0.e_tile);
+  }
   if (force == 0 || cus < 8 || tiles < 1) return 0;
   const long long U = tiles * nk;
   // G is a multiple of 8 (whole XCD groups) and of the column blocks per row tile (a range is
@@ -135,7 +140,11 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_f
       const double s_eff = (double)U / (double)G;
       const double t_sk = a_tiny + s_eff * m.t_plain + ((double)nk / s_eff) * c_seg;
       const double t_plain = m.a_plain + m.t_plain * nk + m.e_tile;
-      return t_sk < 0.9 * t_plain ? (int)G : 0;
+      if (t_sk < 0.9 * t_plain) {
+        if (t_pred) *t_pred = t_sk;
+        return (int)G;
+      }
+      return 0;
     }
   }
   const long long rounds = (tiles + cus - 1) / cus;
@@ -150,13 +159,27 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_f
   const double t_sk2 = G2 ? m.a_sk2 + x * (m.t_sk2 + m.e_tile / nk) : 1e30;
   const long long G = t_sk2 < t_sk1 ? G2 : G1;
   if (force == 1) return (int)G;
-  return (t_sk2 < t_sk1 ? t_sk2 : t_sk1) < 0.99 * t_plain ? (int)G : 0;
+  if ((t_sk2 < t_sk1 ? t_sk2 : t_sk1) < 0.99 * t_plain) {
+    if (t_pred) *t_pred = t_sk2 < t_sk1 ? t_sk2 : t_sk1;
+    return (int)G;
+  }
+  return 0;
 }
 
 // The latency form (conv1x1_small_kernel.h): 16 x 16 output blocks, 4 waves per workgroup, the K loop of a
-// block split over KS of them.  Taken for plain layers (no padded operand, no residual) while even the
-// coarsest decomposition (KS = 1: a workgroup is 16 rows x 64 columns) leaves CUs idle; KS is then the
-// largest of 4 / 2 / 1 whose grid still fits the CUs.  WINO_1X1_ALGO=big|small overrides.
+// block split over KS of them.  For plain layers (no padded operand, no residual) with few pixel rows.
+// Every block pulls its own operands (16 rows of A, 16 columns of B: 128 Cin bytes) through its CU's vector
+// memory path, so the form is bound by bytes and wins while they are few: measured kernel times
+// (profiles/r3: 1 .. 16 images of the four reference layers, KS = 1 / 2 / 4) follow
+//     T = 3.5 us + blocks x 128 Cin bytes / 11 TB/s
+// to about 10 %; the tiled kernel's time comes from sk1_grid's model.  The cheaper prediction wins (M = 196:
+// 1024->256 5.2 us against 19.2, 512->128 4.0 / 10.9, 128->512 3.9 / 6.7, 256->1024 5.7 / 14.6; the tiled
+// kernel takes over at 6-8 images of the 1024->256 and 256->1024 layers, 6 of 128->512, 16 of 512->128).
+// KS: while the coarsest grid (KS = 1: 16 rows x 64 columns per workgroup) leaves CUs idle, the largest of
+// 4 / 2 / 1 whose grid still fits them; beyond one round, the finest split that keeps 128 channels per wave
+// (shorter K loops are all overhead: 256->1024 at 4 images 12.9 us with KS = 2, 18.4 with 4; more, smaller
+// workgroups even out the CUs: 1024->256 at 6 images 25.7 / 21.2 / 19.3 us for KS = 1 / 2 / 4).
+// WINO_1X1_ALGO=big|small and WINO_1X1_SMALL_KS override.
 struct Small1Plan {
   bool use;
   int ks;
@@ -168,13 +191,25 @@ static Small1Plan small1_plan(long M, int Cin, int Kout, int flags, int batch, i
   const Knobs kn = knobs();
   const long long rb = (M + 15) / 16;
   const long long wg1 = rb * (Kout / 64);
-  pl.use = wg1 <= cus;
+  if (rb > 0x7fffffffll || (long long)(Kout / 16) > 65535) return pl;
+  {
+    const double t_small = 3.5 + (double)rb * (Kout / 16) * 128.0 * Cin / 11.0e6;
+    double t_big = 0.0;
+    const bool four = four_waves(Cin, Kout);
+    const int bn = four ? 64 : 128;
+    (void)sk1_grid(((M + BM - 1) / BM) * (long long)(Kout / bn), Cin / 32, cus, Kout / bn, four, &t_big);
+    pl.use = t_small < t_big;
+  }
+  if (kn.sk_1x1 != -1 || kn.sk_1x1_grid != 0) pl.use = false;   // a developer is forcing a form of the tiled kernel
   if (kn.algo_1x1 == 1) pl.use = false;
-  if (kn.algo_1x1 == 2) pl.use = rb <= 0x7fffffffll && Kout / 16 <= 65535;
+  if (kn.algo_1x1 == 2) pl.use = true;
   if (!pl.use) return pl;
   pl.ks = 1;
-  for (int ks = 4; ks > 1; ks >>= 1)
-    if (Cin % (16 * ks) == 0 && wg1 * ks <= cus) { pl.ks = ks; break; }
+  for (int ks = 4; ks > 1; ks >>= 1) {
+    if (Cin % (16 * ks) != 0) continue;
+    if (wg1 <= cus ? wg1 * ks <= cus : Cin / ks >= 128) { pl.ks = ks; break; }
+  }
+  if ((kn.small_ks == 1 || kn.small_ks == 2 || kn.small_ks == 4) && Cin % (16 * kn.small_ks) == 0) pl.ks = kn.small_ks;
   pl.wgs = wg1 * pl.ks;
   return pl;
 }

@@ -48,6 +48,11 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
   const int nsc = kspan >> 4;
   long m = m0 + r16;
   m = m < M ? m : M - 1;                   // rows past the end read a valid row (never stored)
+  // folded BN of this lane's four out-channels: requested now, used at the very end
+  const int ch = n0 + 4 * h;
+  f32x4 sc, bi;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { sc[j] = bnScale[ch + j]; bi[j] = bnBias[ch + j]; }
   const float* ap = A + m * Cin + kq * kspan + 4 * h;
   const float* bp = B + (size_t)(kq * kspan + 4 * h) * Kout + n0 + r16;
 
@@ -97,10 +102,6 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
     for (int j = 1; j < KS; j++) acc += red[w + j][lane];
   }
   // epilogue: lane (r16, h) holds out-channels n0 + 4 h + 0..3 of pixel row m0 + r16
-  const int ch = n0 + 4 * h;
-  f32x4 sc, bi;
-#pragma unroll
-  for (int j = 0; j < 4; j++) { sc[j] = bnScale[ch + j]; bi[j] = bnBias[ch + j]; }
   f32x4 val = sc * acc + bi;
   if (relu) {
 #pragma unroll

@@ -127,6 +127,10 @@ wino_f2_small_kernel(const SmallParams prm) {
   const float* b_src = Uq + (size_t)(h >> 1) * b_chunk_stride + ((size_t)kb * 16 * 64 + kl) * 8 +
                        (((h & 1) ^ ((kl >> 3) & 1)) << 2) + (size_t)(PR * prg) * 4 * 512;   // the wave's first point
 
+  // folded BN of this lane's out-channel: requested now, used by the finisher at the very end (loaded there,
+  // the two values were one more memory round trip on the launch's critical path)
+  const float sc = prm.bnScale[k], bi = prm.bnBias[k];
+
   f32x4 acc[NPT];
 #pragma unroll
   for (int e = 0; e < NPT; e++) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -281,11 +285,8 @@ wino_f2_small_kernel(const SmallParams prm) {
   }
 
   // ---- finalize: BN + ReLU + store (and the block's share of the zero ring)
-  const float* __restrict__ bnScale = prm.bnScale;
-  const float* __restrict__ bnBias = prm.bnBias;
   float* __restrict__ out = prm.out;
   const int relu = prm.relu;
-  const float sc = bnScale[k], bi = bnBias[k];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int gt = tb16 * 16 + 4 * h + r;

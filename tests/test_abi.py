@@ -275,6 +275,49 @@ def test_one_by_one_plan_covers_every_step_once(M, Cin, Kout, cus, grid_env, pkg
         assert rs == list(range(rs[0], rs[0] + len(rs))) and len(rs) >= 2 and segs[0][0] == 0
 
 
+def test_latency_plans_at_the_reference_point(pkg, knobs):
+    """The reference's own protocol is ONE image (`./Test 0..5`).  On 256 CUs the policy must put those layers
+    on (nearly) every CU: the 3x3 layers as 64 blocks x 4 C-splits (256 channels) / 32 blocks x 8 with one
+    point row per task (128 channels), the 1x1 layers as 16 x 16 blocks with the K-split that fills the CUs;
+    and hand over to the throughput / tiled kernels where the measurements (profiles/r3) say so."""
+    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SK",
+              "WINO_1X1_SK_GRID"):
+        knobs.unset(k)
+    assert pkg.small_plan_3x3(1, 256, 256, cus=256) == (1, 4, 4, 256)
+    assert pkg.small_plan_3x3(1, 128, 128, cus=256) == (1, 1, 8, 256)
+    assert pkg.small_plan_3x3(2, 256, 256, cus=256)[:3] == (1, 4, 2)
+    assert pkg.small_plan_3x3(5, 256, 256, cus=256)[:3] == (1, 4, 1)       # 256 blocks: one round, no split
+    assert pkg.small_plan_3x3(6, 256, 256, cus=256)[0] == 0                # a second round: the throughput kernel
+    assert pkg.small_plan_3x3(10, 128, 128, cus=256)[0] == 1 and pkg.small_plan_3x3(11, 128, 128, cus=256)[0] == 0
+    assert pkg.small_plan_3x3(1, 24, 64, cus=256)[0] == 0                  # C % 16: throughput kernel only
+    assert pkg.small_plan_3x3(1, 256, 256, cus=256, H=28, W=28)[0] == 0    # 14x14 only
+    # every wave of the S workgroups gets a task: 4 S <= (C / 16) * (4 / PR)
+    for C in (16, 32, 48, 64, 96, 128, 192, 256, 384, 512):
+        for N in (1, 2, 3, 5):
+            use, pr, sp, wgs = pkg.small_plan_3x3(N, C, 64, cus=256)
+            if use and sp > 1:
+                assert 4 * sp <= (C // 16) * (4 // pr) and 1 <= sp <= 8 and pr in (1, 2, 4), (C, N, pr, sp)
+                assert wgs <= 256
+    want = {(1024, 256): (1, 4, 208), (512, 128): (1, 4, 104), (128, 512): (1, 2, 208), (256, 1024): (1, 1, 208)}
+    for (cin, kout), plan in want.items():
+        assert pkg.small_plan_1x1(196, cin, kout, cus=256) == plan, (cin, kout)
+    # where the tiled kernel takes over (images): measured crossovers, profiles/r3
+    for (cin, kout), (last_small, first_big) in {(1024, 256): (6, 8), (512, 128): (12, 20), (128, 512): (4, 8),
+                                                 (256, 1024): (4, 8)}.items():
+        assert pkg.small_plan_1x1(last_small * 196, cin, kout, cus=256)[0] == 1, (cin, kout, last_small)
+        assert pkg.small_plan_1x1(first_big * 196, cin, kout, cus=256)[0] == 0, (cin, kout, first_big)
+    assert pkg.small_plan_1x1(128 * 196, 1024, 256, cus=256)[0] == 0
+    # a developer forcing a form of the tiled kernel gets the tiled kernel
+    knobs.set("WINO_1X1_SK", "1")
+    assert pkg.small_plan_1x1(196, 1024, 256, cus=256)[0] == 0
+    knobs.unset("WINO_1X1_SK")
+    knobs.set("WINO_1X1_ALGO", "big")
+    assert pkg.small_plan_1x1(196, 1024, 256, cus=256)[0] == 0
+    knobs.set("WINO_1X1_ALGO", "small")
+    knobs.set("WINO_1X1_SMALL_KS", "2")
+    assert pkg.small_plan_1x1(50 * 196, 1024, 256, cus=256)[:2] == (1, 2)
+
+
 def test_one_by_one_plan_rejects_bad_shapes(pkg):
     v = [ctypes.c_int() for _ in range(5)]
     a = [ctypes.byref(x) for x in v]

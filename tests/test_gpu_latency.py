@@ -77,17 +77,6 @@ def test_conv3x3_latency_forms_agree(N, C, K, pkg, O, torch_dev, knobs):
     assert pkg.tickets_in_use() == 0
 
 
-@pytest.mark.parametrize("C", [128, 256])
-def test_conv3x3_latency_policy_at_the_reference_point(C, pkg, torch_dev):
-    """N = 1 on 256 CUs: the policy must put the layer on (nearly) every CU -- 64 blocks x 4 at 256 channels,
-    32 blocks x 8 at 128 -- and the automatic path must be the latency kernel."""
-    use, pr, sp, wgs = pkg.small_plan_3x3(1, C, C, cus=256)
-    assert use == 1 and wgs == 256, (use, pr, sp, wgs)
-    assert (pr, sp) == ((4, 4) if C == 256 else (1, 8))
-    # one image more than fits a round of blocks goes to the throughput kernel
-    assert pkg.small_plan_3x3(6 if C == 256 else 11, C, C, cus=256)[0] == 0
-
-
 def test_conv3x3_latency_with_a_competing_stream(pkg, torch_dev, knobs):
     """Split blocks while a second stream's launches hold CUs: the S workgroups of a block then start at
     different times and any of them may be the finisher.  Bitwise equal results, counters at zero."""
@@ -162,14 +151,6 @@ def test_one_by_one_latency_forms_agree(M, Cin, Kout, relu, pkg, torch_dev, knob
         outs[algo] = out
     assert float((outs["small"] - outs["big"]).abs().max()) < 4e-6 * scale
     assert pkg.tickets_in_use() == 0
-
-
-def test_one_by_one_latency_policy_at_the_reference_point(pkg):
-    """M = 196 on 256 CUs: all four reference layers take the latency form, with the K-split that fills the CUs."""
-    want = {(1024, 256): (1, 4, 208), (512, 128): (1, 4, 104), (128, 512): (1, 2, 208), (256, 1024): (1, 1, 208)}
-    for (cin, kout), plan in want.items():
-        assert pkg.small_plan_1x1(196, cin, kout, cus=256) == plan, (cin, kout)
-    assert pkg.small_plan_1x1(128 * 196, 1024, 256, cus=256)[0] == 0
 
 
 # ------------------------------------------------------------------ recovery after an aborted launch

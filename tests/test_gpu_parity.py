@@ -307,6 +307,7 @@ def test_conv1x1_streamk_with_a_competing_stream(pkg, torch_dev, knobs):
     the reference's 1024->256 (stream-K at N = 128, split-K at N = 2) and a forced grid beyond the resident
     capacity (two 8-wave workgroups per CU)."""
     torch, dev = torch_dev
+    knobs.set("WINO_1X1_ALGO", "big")   # the tiled kernel's hand-over forms are what is tested (N = 2 would take the latency form)
     g = torch.Generator(device="cpu").manual_seed(23)
     mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
     xs, ws, vs = mk(64, 16, 16, 128), mk(128, 128, 3, 3), mk(128)

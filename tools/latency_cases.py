@@ -1,0 +1,101 @@
+"""Developer tool, run under `rocprofv3 --kernel-trace`: every small-batch case launches its kernel REPS times,
+in a fixed order that is printed as JSON (one line per case: name + launches), so that tools/trace_split.py can
+cut the kernel trace into cases by counting dispatches.  Kernel durations come from the trace, not from here
+(back-to-back launches through Python are host-bound at ~10 us each).
+    python tools/latency_cases.py [quick|full]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+dev = torch.device("cuda:0")
+L = pkg.lib()
+REPS = 60
+mode = sys.argv[1] if len(sys.argv) > 1 else "quick"
+
+
+def knob(**kw):
+    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS"):
+        os.environ.pop(k, None)
+    for k, v in kw.items():
+        os.environ[k] = str(v)
+    L.wino_debug_reload_knobs()
+
+
+cases = []
+
+
+def run(name, fn):
+    for _ in range(REPS):
+        fn()
+    torch.cuda.synchronize()
+    cases.append({"case": name, "launches": REPS})
+
+
+def conv3(C, N, **kw):
+    w = (torch.rand(C, C, 3, 3) - 0.5).to(dev)
+    s, b = (torch.rand(C) - 0.5).to(dev), (torch.rand(C) - 0.5).to(dev)
+    U = pkg.filter_transform_f2(w)
+    x = (torch.rand(N, 16, 16, C) - 0.5).to(dev)
+    out = torch.empty(N, 16, 16, C, device=dev)
+    torch.cuda.synchronize()
+    knob(**kw)
+    tag = " ".join("%s=%s" % (k.replace("WINO_", "").lower(), v) for k, v in kw.items()) or "auto"
+    use, pr, sp, wgs = pkg.small_plan_3x3(N, C, C)
+    form = "small pr%d s%d" % (pr, sp) if use else "big"
+    run("3x3 C=%d N=%d [%s -> %s]" % (C, N, tag, form), lambda: pkg.conv3x3_bn_relu(x, U, b, s, out=out))
+    knob()
+
+
+def conv1(Cin, Kout, N, **kw):
+    Bm = ((torch.rand(Cin, Kout) - 0.5) * 4).to(dev)
+    s, b = (torch.rand(Kout) - 0.5).to(dev), (torch.rand(Kout) - 0.5).to(dev)
+    A = ((torch.rand(N * 196, Cin) - 0.5) * 4).to(dev)
+    out = torch.empty(N * 196, Kout, device=dev)
+    torch.cuda.synchronize()
+    knob(**kw)
+    tag = " ".join("%s=%s" % (k.replace("WINO_", "").lower(), v) for k, v in kw.items()) or "auto"
+    use, ks, wgs = pkg.small_plan_1x1(N * 196, Cin, Kout)
+    form = "small ks%d" % ks if use else "big"
+    run("1x1 %d->%d N=%d [%s -> %s]" % (Cin, Kout, N, tag, form), lambda: pkg.conv1x1_bn(A, Bm, b, s, True, out=out))
+    knob()
+
+
+small = lambda pr, sp: dict(WINO_3X3_ALGO="small", WINO_SMALL_PR=pr, WINO_SMALL_SPLIT=sp)
+if mode == "explore":   # beyond one round of blocks / workgroups: where do the latency forms stop paying?
+    for N in (6, 8, 10, 12, 16, 20, 24):
+        conv3(128, N, WINO_3X3_ALGO="big")
+        for pr, sp in ((4, 1), (2, 1), (1, 1), (2, 2), (1, 2)):
+            conv3(128, N, **small(pr, sp))
+    for N in (3, 4, 5, 6, 8):
+        conv3(256, N, WINO_3X3_ALGO="big")
+        for pr, sp in ((4, 1), (2, 1), (1, 1), (2, 2), (1, 2), (1, 4)):
+            conv3(256, N, **small(pr, sp))
+    for Cin, Kout in ((1024, 256), (512, 128), (128, 512), (256, 1024)):
+        for N in (1, 2, 3, 4, 6, 8, 12, 16):
+            conv1(Cin, Kout, N, WINO_1X1_ALGO="big")
+            for ks in (1, 2, 4):
+                conv1(Cin, Kout, N, WINO_1X1_ALGO="small", WINO_1X1_SMALL_KS=ks)
+    for c in cases:
+        print(json.dumps(c), flush=True)
+    sys.exit(0)
+for C in (256, 128):
+    for N in (1, 2, 3, 4, 5, 6, 8, 16) if mode == "full" else (1, 2, 4, 16):
+        conv3(C, N)
+        conv3(C, N, WINO_3X3_ALGO="big")
+    forms = [(4, 1), (4, 2), (4, 4), (2, 2), (2, 4), (2, 8), (1, 4), (1, 8)]
+    for N in (1, 2, 3, 4) if mode == "full" else (1, 2):
+        for pr, sp in forms:
+            if 4 * sp <= (C // 16) * (4 // pr) and ((N * 49 + 15) // 16) * (C // 16) * sp <= 512:
+                conv3(C, N, **small(pr, sp))
+for Cin, Kout in ((1024, 256), (512, 128), (128, 512), (256, 1024)):
+    for N in (1, 2, 3, 4, 6, 8) if mode == "full" else (1, 2, 4):
+        conv1(Cin, Kout, N)
+        conv1(Cin, Kout, N, WINO_1X1_ALGO="big")
+        conv1(Cin, Kout, N, WINO_1X1_ALGO="small")
+for c in cases:
+    print(json.dumps(c), flush=True)
