@@ -105,14 +105,37 @@ def dist_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def dist_init(backend: str):
-    """One process per GPU; the process group exists only for barrier + max(time)."""
+def die(rank: int, stage: str, exc: BaseException):
+    """A failure of the process-group plumbing (RCCL init, a barrier, the max-reduce) must be diagnosable from the
+    driver's record alone: one line on stderr naming the rank, the stage and the error, then a non-zero exit."""
+    import traceback
+    sys.stderr.write(json.dumps({"bench_error": stage, "rank": rank, "error": f"{type(exc).__name__}: {exc}"}) + "\n")
+    traceback.print_exc()
+    sys.stderr.flush()
+    os._exit(3)
+
+
+def dist_init(backend: str, device=None):
+    """One process per GPU; the process group exists only for barrier + max(time).  With RCCL ("nccl") the
+    communicator is bound to this rank's device and exercised once right away (a 1-element max-reduce), so that
+    a broken fabric / IPC set-up fails here, with the rank named, and not inside the timed region."""
+    import torch
     import torch.distributed as dist
     rank, local_rank, world = dist_env()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            if backend == "nccl" and device is not None:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            probe = torch.tensor([float(rank)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+            if int(probe.item()) != world - 1:
+                raise RuntimeError(f"max-reduce over ranks returned {probe.item()}, expected {world - 1}")
+        except Exception as e:   # noqa: BLE001 -- anything here is fatal and must name the rank
+            die(rank, f"process group init ({backend})", e)
     return rank, local_rank, world
 
 
@@ -242,10 +265,11 @@ def main():
     # RCCL ("nccl") is the backend; WINO_BENCH_BACKEND=gloo rehearses the multi-rank control flow
     # on a box with fewer GPUs than ranks (ranks then share devices round-robin)
     backend = os.environ.get("WINO_BENCH_BACKEND", "nccl")
-    rank, local_rank, world = dist_init(backend)
+    _, local_rank, _ = dist_env()
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rank, local_rank, world = dist_init(backend, dev)
     red_dev = dev if backend == "nccl" else None
 
     kind, C, K, relu = LAYERS[args.layer]
@@ -299,7 +323,13 @@ def main():
         torch.cuda.synchronize(dev)
     if world > 1:
         import torch.distributed as dist
-        barrier = (lambda: dist.barrier(device_ids=[dev_index])) if backend == "nccl" else dist.barrier
+        raw_barrier = (lambda: dist.barrier(device_ids=[dev_index])) if backend == "nccl" else dist.barrier
+
+        def barrier():
+            try:
+                raw_barrier()
+            except Exception as e:   # noqa: BLE001
+                die(rank, "barrier", e)
     else:
         barrier = lambda: None
 
@@ -335,7 +365,10 @@ def main():
     for _ in range(max(1, args.trials)):
         state["n"] = 0
         t = timed_steps(step_with_events, args.steps, 0, sync, barrier)
-        t = max_over_ranks(t, world, red_dev)
+        try:
+            t = max_over_ranks(t, world, red_dev)
+        except Exception as e:   # noqa: BLE001
+            die(rank, "max over ranks", e)
         clk = None
         if clock_kernel is not None:
             try:

@@ -105,13 +105,14 @@ def test_entry_point_outputs_match_the_oracle(mode, data_dir, pkg, O, golden_out
     assert O.rel_error(got.reshape(want.shape), want) < TIGHT
 
 
-@pytest.mark.parametrize("mode,N,G", [(1, 8, 2), (1, 9, 4), (4, 6, 2), (0, 128, 2)])
+@pytest.mark.parametrize("mode,N,G", [(1, 8, 2), (1, 9, 4), (4, 6, 2), (0, 128, 2), (1, 128, 8)])
 def test_multi_gpu_driver_path_on_one_gpu(mode, N, G, data_dir, pkg, O):
     """layer_driver.c's batch split -- one host thread and one stream per job, common start barrier,
     per-job slices of the host tensors, (last finish - first start) timing -- run with G jobs aliased
     onto the one visible GPU (WINO_GPUS_ALIAS).  Every image must come out as in the G = 1 run (to
     fp32 summation order: a different per-job batch can take a different launch decomposition), the
-    comparator diff must be clean, and the reported time must cover all jobs."""
+    comparator diff must be clean, and the reported time must cover all jobs.  (1, 128, 8) is the headline
+    layer as an 8-GPU node would split it: eight jobs of 16 images, eight threads and streams in one process.)"""
     L = pkg.lib()
     cwd = os.getcwd()
     os.chdir(data_dir)

@@ -59,6 +59,20 @@ def test_batch_split_two_ranks_gloo(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
 
 
+def test_bench_plumbing_failures_name_the_rank():
+    """A failure of the process-group plumbing (RCCL init, barrier, max-reduce) exits non-zero with one JSON line on
+    stderr that names the rank and the stage: a red SCALE record must be diagnosable without a rerun."""
+    import json
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "try:\n    raise RuntimeError('no xGMI peer')\n"
+            "except Exception as e:\n    bench.die(5, 'process group init (nccl)', e)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3
+    first = json.loads(r.stderr.splitlines()[0])
+    assert first == {"bench_error": "process group init (nccl)", "rank": 5, "error": "RuntimeError: no xGMI peer"}
+
+
 def test_flop_accounting():
     sys.path.insert(0, ROOT)
     import bench
@@ -92,27 +106,32 @@ def test_bench_shard_plans(pkg):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("scaling,extra", [("weak", ["--layer", "conv3x3_256"]),
-                                           ("strong", ["--layer", "residual_block", "--batch", "64"])])
-def test_bench_two_ranks_on_one_gpu(scaling, extra, tmp_path):
+@pytest.mark.parametrize("ranks,scaling,extra", [(2, "weak", ["--layer", "conv3x3_256"]),
+                                                 (2, "strong", ["--layer", "residual_block", "--batch", "64"]),
+                                                 (4, "strong", ["--layer", "residual_block", "--batch", "512"])])
+def test_bench_ranks_on_one_gpu(ranks, scaling, extra, tmp_path):
     """The multi-rank path of bench.py itself (process group, barrier, max over ranks, strong / weak
-    shards) rehearsed with two ranks sharing the one visible GPU over gloo -- the command the driver
-    launches for N GPUs, minus RCCL (which needs one device per rank)."""
+    shards) rehearsed with several ranks sharing the one visible GPU over gloo -- the command the driver
+    launches for N GPUs, minus RCCL (which needs one device per rank).  The 4-rank case is BASELINE
+    configs[4]'s per-GPU share (128 images of the bottleneck block per rank, a strong split of 512); the GPU
+    boxes admit at most 6 processes on the card, so the 8-rank job itself cannot be rehearsed on one GPU."""
     import json
     import subprocess
     env = dict(os.environ, WINO_BENCH_BACKEND="gloo")
-    port = 29700 + os.getpid() % 200
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    port = 29700 + (os.getpid() + 7 * ranks) % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "5", "--warmup", "2", "--preheat-ms", "20", "--scaling", scaling,
+           "--gpus", str(ranks), "--steps", "3" if ranks > 2 else "5", "--warmup", "2", "--preheat-ms", "20", "--scaling", scaling,
            "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout          # rank 0 alone prints
     js = json.loads(lines[0])
-    assert js["n_gpus"] == 2 and js["scaling"] == scaling and js["value"] > 0
-    if scaling == "strong":
+    assert js["n_gpus"] == ranks and js["scaling"] == scaling and js["value"] > 0
+    if ranks == 4:
+        assert js["config"]["global_batch"] == 512 and js["config"]["per_gpu_batch"] == 128
+    elif scaling == "strong":
         assert js["config"]["global_batch"] == 64 and js["config"]["per_gpu_batch"] == 32
     else:
         assert js["config"]["global_batch"] == 256 and js["config"]["per_gpu_batch"] == 128
