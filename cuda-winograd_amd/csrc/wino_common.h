@@ -46,6 +46,8 @@ struct Knobs {
   int algo_3x3;       // WINO_3X3_ALGO: 0 automatic, 1 "big" (throughput kernel), 2 "small" (latency kernel)
   int sk_1x1;         // WINO_1X1_SK: -1 automatic, 0 plain form, 1 stream-K whenever a legal grid exists
   int sk_1x1_grid;    // WINO_1X1_SK_GRID: number of ranges (0 = model)
+  int sk_kp;          // WINO_SK_KP: 1 (default) the 3x3 stream-K tail per k-block, ranges placed in phase order; 0 round 2's
+                      // item-major list in launch order; 2 / 3 only the groups / only the phase order (A/B measurements)
   int small_split;    // WINO_SMALL_SPLIT: C-split S of the 3x3 latency kernel (0 = policy)
   int small_pr;       // WINO_SMALL_PR: point rows per task of the 3x3 latency kernel, 1 / 2 / 4 (0 = policy)
   int algo_1x1;       // WINO_1X1_ALGO: 0 automatic, 1 "big" (LDS-staged kernel), 2 "small" (latency kernel)

@@ -257,6 +257,33 @@ static int sk_grid_for(int cus, long long items, int nchunks, int* G) {
   return WINO_OK;
 }
 
+// k-groups of the stream-K tail (wino_f2_fused_kernel.h): K/64 when the grid is a multiple of it -- the items are
+// K/64 per tile block, so the tail's item count is then a multiple too -- else 1 (one item-major list, round 2's
+// scheme).  WINO_SK_KP=0 forces round 2's scheme altogether (A/B measurements).
+static int tail_groups(int G, int K) {
+  const int kblk = K / KB;
+  if (knobs().sk_kp == 0 || knobs().sk_kp == 3 || kblk <= 1 || (G % kblk) != 0) return 1;
+  return kblk;
+}
+
+// Phase order of a k-group's tail ranges (tail_range_of, wino_f2_fused_kernel.h): for Gp equal ranges of q iterations
+// the period P = nchunks / gcd(q, nchunks) of their channel phases, the inverse of q / gcd modulo P, and Gp / P.
+struct PhaseOrder { int P, inv, copies; };
+static PhaseOrder phase_order(long long q, long long rem, int nchunks, long long Gp) {
+  PhaseOrder id = {1, 0, (int)Gp};
+  if (rem != 0 || q <= 0 || knobs().sk_kp == 0 || knobs().sk_kp == 2) return id;   // (WINO_SK_KP=0: round 2's scheme; 2: k-groups without the phase order; 3: phase order without the groups -- A/B)
+  long long a = q % nchunks, b = nchunks;
+  while (a) { const long long t = b % a; b = a; a = t; }
+  const long long g = b, P = nchunks / g;
+  if (P <= 1 || Gp % P != 0) return id;
+  const long long qq = (q / g) % P;
+  long long inv = 0;
+  for (long long x = 1; x < P; x++)
+    if ((qq * x) % P == 1) { inv = x; break; }
+  if (!inv) return id;
+  return PhaseOrder{(int)P, (int)inv, (int)(Gp / P)};
+}
+
 // The largest batch one launch takes: the kernels address the tensors with 32-bit byte offsets
 // (both tensors must stay below 4 GiB) and the stream-K bookkeeping counts chunk iterations in
 // 32 bits.  Larger batches are split by the launcher (images are independent).
@@ -426,9 +453,12 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
   SkBufs bufs;
   if (int rc = sk_workspace(dev, s, G, items, &bufs)) return rc;
   const long long Tt = (long long)(items % (size_t)G) * (C / BC);   // the stream-K tail's iterations
+  const int kp = tail_groups(G, K);                                   // ... cut per k-block when the grid allows it
+  const long long Tg = Tt / kp, Gp = G / kp;
   const Geo geo = {H + 2, W + 2, tiles, tiles_x, make_fastdiv(tiles), make_fastdiv(tiles_x)};
-  const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
-                           geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, nullptr};
+  const PhaseOrder po = phase_order(Tg / Gp, Tg % Gp, C / BC, Gp);
+  const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tg / Gp), (unsigned)(Tg % Gp), kp,
+                           po.P, po.inv, po.copies, geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, nullptr};
   // whole items only (no stream-K tail): the kernel variant without the hand-off in its epilogue
   if (Tt == 0) return fixed14 ? launch_fused<false, false>(prm, G, dev, s) : launch_fused<true, false>(prm, G, dev, s);
   return fixed14 ? launch_fused<false, true>(prm, G, dev, s) : launch_fused<true, true>(prm, G, dev, s);
@@ -453,9 +483,12 @@ static int conv3x3_clock_probe(const float* in, const float* U, const float* bnB
   SkBufs bufs;
   if (int rc = sk_workspace(dev, s, G, items, &bufs)) return rc;
   const long long Tt = (long long)(items % (size_t)G) * (C / BC);
+  const int kp = tail_groups(G, K);
+  const long long Tg = Tt / kp, Gp = G / kp;
   const Geo geo = {WINO_HW, WINO_HW, WINO_TILES, 7, make_fastdiv(WINO_TILES), make_fastdiv(7)};
-  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / (size_t)G), (unsigned)(Tt / G), (unsigned)(Tt % G),
-                           geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, stamps};
+  const PhaseOrder po = phase_order(Tg / Gp, Tg % Gp, C / BC, Gp);
+  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / (size_t)G), (unsigned)(Tg / Gp), (unsigned)(Tg % Gp), kp,
+                           po.P, po.inv, po.copies, geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, stamps};
   static std::atomic<unsigned long long> attr_done{0};
   if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
     WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<16, false>),
@@ -508,6 +541,29 @@ int wino_diag_last_clock(int kernel, wino_stream_t s, unsigned long long stamps[
   WINO_HIP(hipStreamSynchronize((hipStream_t)s));
   if (kernel == 1) return wino::last_clock_1x1(stamps);
   WINO_HIP(hipMemcpyFromSymbol(stamps, HIP_SYMBOL(wino::fused::wino_clk_slot_3x3), 4 * sizeof(unsigned long long)));
+  return WINO_OK;
+}
+
+// Host-side only: into how many k-groups the launch wino_conv3x3_plan describes cuts its tail (1 = one item-major
+// list).  Group k owns the tail items of out-channel block k, item rounds*grid + groups*j + k for j = 0, 1, ...;
+// its tail_iters / groups iterations are cut into Gp = grid / groups equal ranges [r*T/Gp, (r+1)*T/Gp), and the
+// workgroup l = groups*j + k at position j runs range r = (phase_inv * (j / phase_copies)) % phase_period +
+// phase_period * (j % phase_copies) -- the ranges of one XCD's workgroups start at consecutive channel phases.
+int wino_conv3x3_plan_groups(int N, int H, int W, int C, int K, int cus, int* groups, int* phase_period, int* phase_inv,
+                             int* phase_copies) {
+  if (!groups || !phase_period || !phase_inv || !phase_copies || cus < 1) { set_error("bad argument"); return WINO_E_ARG; }
+  if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
+  const long long nTB = ((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + TB - 1) / TB;
+  const long long items = nTB * (K / KB);
+  int G = 0;
+  if (int rc = sk_grid_for(cus, items, C / BC, &G)) return rc;
+  const int kp = tail_groups(G, K);
+  const long long Tg = (items % G) * (C / BC) / kp, Gp = G / kp;
+  const PhaseOrder po = phase_order(Tg / Gp, Tg % Gp, C / BC, Gp);
+  *groups = kp;
+  *phase_period = po.P;
+  *phase_inv = po.inv;
+  *phase_copies = po.copies;
   return WINO_OK;
 }
 

@@ -146,6 +146,17 @@ __host__ __device__ inline unsigned sk_start(unsigned l, unsigned q, unsigned re
   return l * q + l * rem / G;
 }
 
+// Which of a k-group's Gp tail ranges the workgroup at position j (consecutive positions share an XCD) runs.  Ranges
+// of equal length q start at channel phase (q * range) mod nchunks, which repeats with period P = nchunks / gcd(q,
+// nchunks); ranked by phase, rank r belongs to the ranges a + P * b with a = inv * r mod P.  Position j = r * copies +
+// b, so that the workgroups of one XCD hold ranges of CONSECUTIVE phases: a filter chunk (k-block, channel chunk) one
+// of them has fetched is what its neighbours ask for one iteration later -- an L2 hit instead of a fetch per
+// workgroup.  P = 1, inv = 0, copies = Gp is the identity (unequal ranges, or a period that does not divide Gp).
+__host__ __device__ inline int tail_range_of(int j, int P, int inv, int copies) {
+  const int r = j / copies, b = j - r * copies;
+  return (inv * r) % P + P * b;
+}
+
 // The kernel's only argument.  The fields below the line are used by the epilogue alone: it
 // re-reads them from the kernarg segment each time instead of keeping ~20 scalar registers
 // (pointers + two buffer descriptors) alive across the main loop, which is out of SGPRs.
@@ -154,7 +165,9 @@ struct FusedParams {
   const float* Uq;
   int N, C, K, relu, nTB;
   int ndp;                     // whole-item rounds: items / gridDim.x
-  unsigned sk_q, sk_rem;       // tail: (items % gridDim.x) * C/8 = sk_q * gridDim.x + sk_rem iterations
+  unsigned sk_q, sk_rem;       // tail, per k-group: (items % gridDim.x) / kp * C/8 = sk_q * (gridDim.x / kp) + sk_rem iterations
+  int kp;                      // k-groups of the tail: K/64 (gridDim.x a multiple of it) or 1
+  int ph_P, ph_inv, ph_copies; // which tail range the j-th position of a group runs (tail_range_of below)
   Geo geo;                     // feature-map geometry (read by the GEN = true build only)
   // ---- epilogue only ----
   const float* bnBias;
@@ -213,10 +226,20 @@ wino_f2_fused_kernel(const FusedParams prm) {
       wino_clk_slot_3x3[3] = __builtin_amdgcn_s_memrealtime();
     }
   };
-  // tail: items ndp*G .. , (sk_q * G + sk_rem) chunk iterations in item-major order; then the rounds
+  // tail: items ndp*G .. ; then the rounds.  The tail is cut PER OUT-CHANNEL BLOCK (kp = K/64 groups when the grid
+  // is a multiple of it): group k = lg % kp owns the tail items of k-block k (one per tile block, walked in
+  // tile-block order: item tail_item0 + kp*j + k), (sk_q * Gp + sk_rem) chunk iterations cut into Gp = G / kp equal
+  // ranges, range lp = lg / kp.  The kp workgroups with the same lp -- neighbours on one XCD -- then walk the SAME
+  // tile blocks and channel chunks at the same time and share every patch line in the XCD's L2, exactly as the
+  // whole-item rounds do.  (Round 2 cut one item-major list into G ranges: the k-blocks of a tile block sat at
+  // different channel phases, every one of them fetched the patches for itself: HBM-side fetch 164 MB per launch
+  // at the reference's 256 channels, N = 128, against 38 MB compulsory.)  kp = 1 is that old scheme.
   const int tail_item0 = ndp * G;
-  const unsigned t_begin = __builtin_amdgcn_readfirstlane(sk_start(lg, sk_q, sk_rem, G));
-  const int Lt = (int)(__builtin_amdgcn_readfirstlane(sk_start(lg + 1, sk_q, sk_rem, G)) - t_begin);   // tail iterations of this workgroup
+  const int kpg = prm.kp;
+  const int lpos = __builtin_amdgcn_readfirstlane(kpg > 1 ? lg / kpg : lg), grp = lg - lpos * kpg, Gp = kpg > 1 ? G / kpg : G;
+  const int lp = __builtin_amdgcn_readfirstlane(tail_range_of(lpos, prm.ph_P, prm.ph_inv, prm.ph_copies));   // the group's tail range this workgroup runs
+  const unsigned t_begin = __builtin_amdgcn_readfirstlane(sk_start(lp, sk_q, sk_rem, Gp));
+  const int Lt = (int)(__builtin_amdgcn_readfirstlane(sk_start(lp + 1, sk_q, sk_rem, Gp)) - t_begin);   // tail iterations of this workgroup
   const int L = Lt + ndp * nchunks;                                     // all its chunk iterations
 
   // ---- ring pass: the output's zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:
@@ -423,7 +446,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
       dma_set_item(lg);
     } else if (++d_chunk == nchunks) {
       d_chunk = 0;
-      dma_set_item(d_tail > 0 ? d_item + 1 : d_item + G);
+      dma_set_item(d_tail > 0 ? d_item + kernarg()->kp : d_item + G);   // the next tail item of this k-group / round
     } else {
       d_soff_raw += (unsigned)(BC * sizeof(float));
       d_soff_u += u_chunk_stride;
@@ -457,7 +480,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
   // (The current item and the kind of the current segment are looked at by the epilogue and the segment switch
   //  only: they ride through the main loop in VGPRs, like pend_vg below, and are read back with readfirstlane
   //  where they are needed.  The loop has no SGPR to spare.)
-  int c_item_vg = __builtin_amdgcn_readfirstlane(Lt > 0 ? tail_item0 + (int)(t_begin / (unsigned)nchunks) : lg);
+  int c_item_vg = __builtin_amdgcn_readfirstlane(Lt > 0 ? tail_item0 + (int)(t_begin / (unsigned)nchunks) * kpg + grp : lg);
   int c_chunk = __builtin_amdgcn_readfirstlane(Lt > 0 ? (int)(t_begin % (unsigned)nchunks) : 0);
   int seg_kind_vg = 0;             // bit 1: the current segment starts its item, bit 0: it is the whole item
   // a partial segment whose ticket is drawn in the next epilogue (-1: none).  Parked in a VGPR across the
@@ -707,6 +730,9 @@ wino_f2_fused_kernel(const FusedParams prm) {
     const int N = kp->N, K = kp->K, relu = kp->relu, KBLK = K >> 6, totalTiles = N * (GEN ? (int)geo.tiles : WINO_TILES);
     const unsigned sk_q = kp->sk_q, sk_rem = kp->sk_rem;
     const int tail_item0 = kp->ndp * G;
+    const int kpg = kp->kp;   // k-groups of the tail; this workgroup is range lp_e of group grp_e
+    const int lpos_e = kpg > 1 ? lg / kpg : lg, grp_e = lg - lpos_e * kpg, Gp = kpg > 1 ? G / kpg : G;
+    const int lp_e = tail_range_of(lpos_e, kp->ph_P, kp->ph_inv, kp->ph_copies);   // slab slots are numbered by (tail range, group)
     const float* bnBias = kp->bnBias;
     const float* bnScale = kp->bnScale;
     unsigned* tickets = kp->tickets;
@@ -814,7 +840,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
     } else if (!(ABLATE & 1024)) {
       // slab slot: 2l for the segment that continues an item (head of l's range), 2l+1 for the
       // one that starts an item
-      const unsigned my_slot = 2u * lg + ((seg_kind & 2) ? 1u : 0u);
+      const unsigned my_slot = 2u * (unsigned)(lp_e * kpg + grp_e) + ((seg_kind & 2) ? 1u : 0u);
 #pragma unroll
       for (int q = 0; q < 8; q++)
         slab_store16(y[q >> 1][q & 1], rsrc_slab, slab_voff + q * 1024, my_slot * SLAB_BYTES);
@@ -852,13 +878,13 @@ wino_f2_fused_kernel(const FusedParams prm) {
       if (!(j == 0 && whole)) {
         // which logical workgroups share `item`: walk outwards from lg.  With more workgroups
         // than iterations some own nothing; they are not segments.
-        const unsigned x0 = (unsigned)(item - tail_item0) * (unsigned)nchunks, x1 = x0 + nchunks - 1;   // tail space
-        int gA = lg, gB = lg;
-        while (sk_start(gA, sk_q, sk_rem, G) > x0) gA--;
-        while (gB + 1 < G && sk_start(gB + 1, sk_q, sk_rem, G) <= x1) gB++;
+        const unsigned x0 = (unsigned)((item - tail_item0) / kpg) * (unsigned)nchunks, x1 = x0 + nchunks - 1;   // the group's tail space
+        int gA = lp_e, gB = lp_e;
+        while (sk_start(gA, sk_q, sk_rem, Gp) > x0) gA--;
+        while (gB + 1 < Gp && sk_start(gB + 1, sk_q, sk_rem, Gp) <= x1) gB++;
         int nseg = 0;
         for (int g = gA; g <= gB; g++)
-          nseg += sk_start(g + 1, sk_q, sk_rem, G) != sk_start(g, sk_q, sk_rem, G);
+          nseg += sk_start(g + 1, sk_q, sk_rem, Gp) != sk_start(g, sk_q, sk_rem, Gp);
         const unsigned old = __builtin_amdgcn_readfirstlane(j == 0 ? old0 : pend_old);
         if (old != (unsigned)(nseg - 1)) {   // another workgroup's wave w will finish the item
           // ... unless the counter was not zero when the launch began (a launch that died mid-way before this
@@ -874,8 +900,8 @@ wino_f2_fused_kernel(const FusedParams prm) {
         bool first = true;
 #pragma unroll 1
         for (int g = gA; g <= gB; g++) {
-          if (sk_start(g + 1, sk_q, sk_rem, G) == sk_start(g, sk_q, sk_rem, G)) continue;   // owns nothing
-          const unsigned slot = 2u * (unsigned)g + (first ? 1u : 0u);
+          if (sk_start(g + 1, sk_q, sk_rem, Gp) == sk_start(g, sk_q, sk_rem, Gp)) continue;   // owns nothing
+          const unsigned slot = 2u * (unsigned)(g * kpg + grp_e) + (first ? 1u : 0u);   // (tail range g, this group)
           f32x4 t[8];
 #pragma unroll
           for (int q = 0; q < 8; q++) t[q] = slab_load16(rsrc_slab, slab_voff + q * 1024, slot * SLAB_BYTES);
@@ -1028,7 +1054,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
         c_item_vg = lg;
         c_tail_vg = 0;
       } else {
-        c_item_vg += c_tail > 0 ? 1 : G;
+        c_item_vg += c_tail > 0 ? kernarg()->kp : G;
       }
       asm volatile("" : "+v"(c_item_vg), "+v"(c_tail_vg));
     }

@@ -143,6 +143,7 @@ void read_knobs() {
   k.algo_3x3 = algo && !strcmp(algo, "big") ? 1 : algo && !strcmp(algo, "small") ? 2 : 0;
   k.sk_1x1 = env_num("WINO_1X1_SK", -1);
   k.sk_1x1_grid = env_num("WINO_1X1_SK_GRID", 0);
+  k.sk_kp = env_num("WINO_SK_KP", 1);
   k.small_split = env_num("WINO_SMALL_SPLIT", 0);
   k.small_pr = env_num("WINO_SMALL_PR", 0);
   const char* algo1 = getenv("WINO_1X1_ALGO");

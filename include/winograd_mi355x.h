@@ -49,6 +49,7 @@ extern "C" {
  * wino_driver_set_gpu_alias, wino_driver_set_stdout_compat, wino_driver_cpu_baseline,
  * wino_diag_conv3x3_clock, wino_debug_tickets_in_use, wino_stream_check, wino_stream_reset_scratch,
  * wino_debug_poison_ticket, wino_diag_last_clock, wino_conv3x3_small_plan, wino_conv1x1_small_plan,
+ * wino_conv3x3_plan_groups,
  * WINO_E_STATE.  The library-owned stream-K scratch is never freed or moved while its
  * stream lives (it used to be reallocated when a larger shape arrived). */
 #define WINO_ABI_VERSION 1
@@ -161,6 +162,16 @@ int wino_conv3x3_prepare_hw(int N, int H, int W, int C, int K, wino_stream_t s);
  * as a stream-K tail: workgroup l takes tail iterations [l*tail_iters/grid, (l+1)*tail_iters/grid). */
 int wino_conv3x3_plan(int N, int H, int W, int C, int K, int cus, int* grid, int* rounds, long* tail_iters,
                       int* iters_per_item);
+/* Host-side only: how that launch cuts and places its tail.  *groups = 1: one item-major list of tail_iters iterations
+ * as described above; K/64 (taken whenever grid is a multiple of it): one list per out-channel block -- group k owns
+ * the tail items of k-block k (item rounds*grid + groups*j + k, j = 0, 1, ...: one per tile block) and tail_iters /
+ * groups iterations, cut into Gp = grid / groups equal ranges.  The workgroup l = groups*j + k at position j of group
+ * k runs range  (phase_inv * (j / phase_copies)) % phase_period + phase_period * (j % phase_copies)  of its group: a
+ * permutation of 0 .. Gp-1 (the identity for period 1) that gives the workgroups of one XCD -- consecutive positions
+ * -- ranges starting at consecutive channel phases.  The groups' workgroups at one position walk the same tile blocks
+ * and channel chunks in step and share the patches in the XCD's L2; neighbours in phase share the filter chunks. */
+int wino_conv3x3_plan_groups(int N, int H, int W, int C, int K, int cus, int* groups, int* phase_period, int* phase_inv,
+                             int* phase_copies);
 /* Host-side only: whether this shape takes the latency kernel instead (small batches of the 14x14 stage: the
  * reference's own N = 1), and in which form: *point_rows (4, 2 or 1 rows of the 4x4 point grid per wave task)
  * and *split (workgroups that share one 16-tile x 16-out-channel block's contraction, meeting through

@@ -181,13 +181,30 @@ def test_launch_plan_covers_every_iteration_once(N, H, W, C, K, cus, pkg, knobs)
     assert nch == C // 8 and G >= 1 and rounds == items // G
     assert tail_iters == (items % G) * nch
     assert G <= max(cus, 1) or G == items          # at most one workgroup per CU, or one item each
+    # the tail is cut per out-channel block when the grid is a multiple of K/64 (the k-blocks of a tile block then
+    # walk the same patches in step): `groups` lists of tail_iters / groups iterations over G / groups ranges
+    grp, per, inv, cop = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert pkg.lib().wino_conv3x3_plan_groups(N, H, W, C, K, cus, ctypes.byref(grp), ctypes.byref(per), ctypes.byref(inv),
+                                              ctypes.byref(cop)) == 0
+    kp, P, pinv, copies = grp.value, per.value, inv.value, cop.value
+    assert kp in (1, K // 64) and G % kp == 0 and tail_iters % kp == 0
+    assert (kp == K // 64) == (G % (K // 64) == 0)
+    # position j of a group -> the tail range it runs: a permutation of the group's ranges (the identity for period 1)
+    range_of = lambda j: (pinv * (j // copies)) % P + P * (j % copies)
+    assert P * copies == G // kp and sorted(range_of(j) for j in range(G // kp)) == list(range(G // kp))
+    Tg, Gp = tail_iters // kp, G // kp
     seen = np.zeros((items, nch), np.int32)
     loads = []
+    slots = set()
     for l in range(G):
         mine = 0
-        t0, t1 = l * tail_iters // G, (l + 1) * tail_iters // G     # the kernel's sk_start()
+        j, k = divmod(l, kp)
+        lp = range_of(j)
+        t0, t1 = lp * Tg // Gp, (lp + 1) * Tg // Gp     # the kernel's sk_start() in the group's tail space
         for t in range(t0, t1):
-            seen[rounds * G + t // nch, t % nch] += 1
+            item = rounds * G + (t // nch) * kp + k
+            assert item % (K // 64) == k or kp == 1      # group k only ever touches k-block k
+            seen[item, t % nch] += 1
         mine += t1 - t0
         for r in range(rounds):
             seen[r * G + l, :] += 1
@@ -198,6 +215,12 @@ def test_launch_plan_covers_every_iteration_once(N, H, W, C, K, cus, pkg, knobs)
     # the two headline facts of DESIGN.md section 3.1
     if (N, H, C, K, cus) == (128, 14, 256, 256, 256):
         assert (G, rounds, tail_iters) == (256, 1, 136 * 32) and max(loads) == 49
+        # 4 k-groups of 64 ranges of 17 iterations; phases 17 r mod 32 repeat with period 32; an XCD's 8 positions
+        # hold 4 consecutive phases, each twice
+        assert (kp, P, copies) == (4, 32, 2)
+        for x in range(8):
+            phases = sorted((17 * range_of(8 * x + i)) % 32 for i in range(8))
+            assert phases == sorted(2 * [4 * x, 4 * x + 1, 4 * x + 2, 4 * x + 3])
     if (N, H, C, K, cus) == (128, 14, 128, 128, 256):
         assert (G, rounds, tail_iters) == (196, 1, 0)
 

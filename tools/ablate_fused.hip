@@ -31,7 +31,7 @@ float run(const float* in, const float* U, const float* b, const float* s, float
   const int grid = grid_for(N, K);
   CK(hipMemset(g_tickets, 0, 65536 * 4));   // ablated variants may leave tickets behind
   const unsigned items = (unsigned)nTB * (K / KB), Tt = (items % grid) * (C / 8);
-  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / grid), Tt / grid, Tt % grid, Geo{}, b, s, out, g_slabs, g_tickets, g_err, g_dbg};
+  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / grid), Tt / grid, Tt % grid, 1, 1, 0, (int)grid, Geo{}, b, s, out, g_slabs, g_tickets, g_err, g_dbg};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; i++)
