@@ -12,6 +12,7 @@ L = pkg.lib()
 dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 os.environ["WINO_3X3_ALGO"] = "big"
+os.environ["WINO_1X1_ALGO"] = "big"    # the tiled kernel's stream-K / split-K hand-offs are what is soaked (N = 2 would take the latency form)
 torch.manual_seed(0)
 cfgs = []
 for (N, C, K, grid) in [(128, 256, 256, 0), (128, 128, 128, 0), (50, 64, 128, 56), (37, 128, 192, 200), (96, 256, 64, 97),
@@ -28,12 +29,40 @@ for (N, Cin, Kout, grid) in [(128, 1024, 256, 0), (128, 1024, 256, 512), (100, 5
     Bm = torch.rand(Cin, Kout, device=dev) - 0.5
     b, s = torch.rand(Kout, device=dev) - 0.5, torch.rand(Kout, device=dev) - 0.5
     cfg1.append([N, Cin, Kout, grid, A, Bm, b, s, None])
+# 3x3 latency kernel: blocks shared by S workgroups through slabs + one ticket per workgroup (round 3); forms forced
+cfgs_small = []
+for (N, C, K, pr, sp) in [(1, 256, 256, 4, 4), (1, 128, 128, 1, 8), (2, 256, 256, 4, 2), (1, 256, 256, 2, 8), (3, 128, 128, 2, 3),
+                          (2, 128, 128, 1, 4), (1, 64, 192, 1, 4), (4, 128, 128, 4, 2)]:
+    x = torch.rand(N, 16, 16, C, device=dev) - 0.5
+    U = pkg.filter_transform_f2(torch.rand(K, C, 3, 3, device=dev) - 0.5)
+    b, s = torch.rand(K, device=dev) - 0.5, torch.rand(K, device=dev) - 0.5
+    cfgs_small.append([N, C, K, (pr, sp), x, U, b, s, None])
 side = torch.cuda.Stream()
 xs = torch.rand(64, 16, 16, 128, device=dev); Us = pkg.filter_transform_f2(torch.rand(128, 128, 3, 3, device=dev)); vs = torch.rand(128, device=dev)
 use_side = os.environ.get("SOAK_SIDE", "1") != "0"
 t0, launches, bad = time.time(), 0, 0
 stats = {}
 while time.time() - t0 < budget:
+    for c in cfgs_small:
+        N, C, K, (pr, sp), x, U, b, s, ref = c
+        os.environ.update(WINO_3X3_ALGO="small", WINO_SMALL_PR=str(pr), WINO_SMALL_SPLIT=str(sp))
+        os.environ.pop("WINO_SK_GRID", None)
+        L.wino_debug_reload_knobs()
+        if use_side:
+            with torch.cuda.stream(side):
+                for _ in range(2): pkg.conv3x3_bn_relu(xs, Us, vs, vs)
+        outs = [pkg.conv3x3_bn_relu(x, U, b, s) for _ in range(40)]
+        launches += 40
+        if ref is None:
+            c[8] = outs[0].clone(); ref = c[8]
+        for o in outs:
+            if not torch.equal(o, ref):
+                bad += 1
+                st = stats.setdefault(("small", N, C, K, pr, sp), [0, 0.0, 0, 0])
+                d = (o - ref).abs()
+                st[0] += 1; st[1] = max(st[1], float(d.max())); st[2] = max(st[2], int((d > 0).sum())); st[3] = max(st[3], int(torch.isnan(o).sum()))
+    os.environ["WINO_3X3_ALGO"] = "big"
+    for k in ("WINO_SMALL_PR", "WINO_SMALL_SPLIT"): os.environ.pop(k, None)
     for c in cfgs:
         N, C, K, grid, x, U, b, s, ref = c
         if grid: os.environ["WINO_SK_GRID"] = str(grid)
