@@ -191,7 +191,7 @@ static Small1Plan small1_plan(long M, int Cin, int Kout, int flags, int batch, i
   const Knobs kn = knobs();
   const long long rb = (M + 15) / 16;
   const long long wg1 = rb * (Kout / 64);
-  if (rb > 0x7fffffffll || (long long)(Kout / 16) > 65535) return pl;
+  if (rb > 65535) return pl;   // (gridDim.y)
   {
     const double t_small = 3.5 + (double)rb * (Kout / 16) * 128.0 * Cin / 11.0e6;
     double t_big = 0.0;
@@ -215,7 +215,7 @@ static Small1Plan small1_plan(long M, int Cin, int Kout, int flags, int batch, i
 }
 static int launch_1x1_small(const Small1Plan& pl, const float* A, const float* B, const float* bnBias,
                             const float* bnScale, float* C, long M, int Cin, int Kout, int relu, hipStream_t s) {
-  const dim3 grid((unsigned)((M + 15) / 16), (unsigned)(Kout / 64 * pl.ks)), block(256);
+  const dim3 grid((unsigned)(Kout / 64 * pl.ks), (unsigned)((M + 15) / 16)), block(256);   // x = column group: see the kernel
   if (pl.ks == 4) hipLaunchKernelGGL(conv1x1_small_kernel<4>, grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
   else if (pl.ks == 2) hipLaunchKernelGGL(conv1x1_small_kernel<2>, grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
   else hipLaunchKernelGGL(conv1x1_small_kernel<1>, grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);

@@ -42,8 +42,11 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
     wino_clk_slot_1x1[1] = __builtin_amdgcn_s_memrealtime();
   }
   const int r16 = lane & 15, h = lane >> 4;
-  const long m0 = (long)blockIdx.x * 16;
-  const int n0 = ((int)blockIdx.y * CB + cb) * 16;
+  // blockIdx.x = column group: workgroups are dealt to the XCDs round-robin in x-fastest order, so the row blocks
+  // that read one 16*CB-column slice of B share an XCD and its L2 (the column groups are a multiple of 8 for every
+  // Kout % 128 == 0): B is then fetched once per launch instead of once per XCD
+  const long m0 = (long)blockIdx.y * 16;
+  const int n0 = ((int)blockIdx.x * CB + cb) * 16;
   const int kspan = Cin / KS;              // channels this wave contracts (a multiple of 16: checked on the host)
   const int nsc = kspan >> 4;
   long m = m0 + r16;

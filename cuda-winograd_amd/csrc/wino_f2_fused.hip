@@ -347,7 +347,7 @@ static SmallPlan small_plan(int N, int H, int W, int C, int K, int cus) {
   pl.blocks = (size_t)blocks;
   pl.use = blocks <= cus;
   if (kn.algo_3x3 == 1) pl.use = false;
-  if (kn.algo_3x3 == 2) pl.use = blocks <= 65535 * 16ll;
+  if (kn.algo_3x3 == 2) pl.use = pl.nT16 <= 65535;
   if (!pl.use) return pl;
   const int nsuper = C / 16;
   int smax = (int)(cus / blocks);
@@ -436,8 +436,8 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
   if (sp.use) {
     SkBufs bufs;
     if (int rc = small_scratch(dev, s, sp, &bufs)) return rc;
-    const SmallParams prm = {in, U, bnBias, bnScale, out, N, C, K, relu, bufs.slabs, bufs.tickets, bufs.err};
-    const dim3 grid(sp.nT16, K / 16, sp.split), block(64 * SMALL_WAVES);
+    const SmallParams prm = {in, U, bnBias, bnScale, out, N, C, K, relu, bufs.slabs, bufs.tickets, bufs.err, nullptr};
+    const dim3 grid(K / 16, sp.nT16, sp.split), block(64 * SMALL_WAVES);   // x = out-channel block: see the kernel
     if (sp.pr == 4) hipLaunchKernelGGL(wino_f2_small_kernel<4>, grid, block, 0, s, prm);
     else if (sp.pr == 2) hipLaunchKernelGGL(wino_f2_small_kernel<2>, grid, block, 0, s, prm);
     else hipLaunchKernelGGL(wino_f2_small_kernel<1>, grid, block, 0, s, prm);

@@ -53,9 +53,13 @@ struct SmallParams {
   float* slabs;              // [block][S] x 4 KB (S > 1 only)
   unsigned* tickets;         // [block]
   unsigned* err;             // host-visible word: set when a ticket counter was found dirty (S > 1 only)
+  unsigned long long* dbg;   // timeline build only (DIAG, tools/small_timeline): 8 stamps per workgroup
 };
 
-template <int PR>
+// DIAG = true is the timeline build (tools/small_timeline.hip): wave 0 of every workgroup stores s_memrealtime
+// (100 MHz, chip-wide) at entry, operands requested, MFMAs done, LDS level done, slab drained, ticket drawn, gather
+// landed, exit.  The product kernel is DIAG = false.
+template <int PR, bool DIAG = false>
 __global__ void __launch_bounds__(64 * SMALL_WAVES)
 wino_f2_small_kernel(const SmallParams prm) {
   static_assert(PR == 1 || PR == 2 || PR == 4, "point rows per task");
@@ -69,8 +73,19 @@ wino_f2_small_kernel(const SmallParams prm) {
   const int lane = threadIdx.x & 63;
   const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t16 = lane & 15, h = lane >> 4;
-  const int tb16 = blockIdx.x, kq = blockIdx.y;
+  // blockIdx.x = out-channel block: blocks are dealt to the XCDs round-robin in x-fastest order, so the workgroups
+  // that read one filter slice (all tile blocks, all C-splits of a kq) share an XCD and its L2 (K/16 is a multiple of
+  // 8 for every K % 128 == 0); the slice is then fetched once per launch instead of once per tile block
+  const int tb16 = blockIdx.y, kq = blockIdx.x;
   const int S = gridDim.z, split = blockIdx.z;
+  auto mark = [&](int i) {
+    if (DIAG && threadIdx.x == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      prm.dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + i] = __builtin_amdgcn_s_memrealtime();   // (any order: the tool sorts)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  mark(0);
   // in-kernel clock of the launch (wino_diag_last_clock): block 0's first wave stamps its entry and its exit
   const bool clk = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
   if (clk) {
@@ -127,9 +142,12 @@ wino_f2_small_kernel(const SmallParams prm) {
   const float* b_src = Uq + (size_t)(h >> 1) * b_chunk_stride + ((size_t)kb * 16 * 64 + kl) * 8 +
                        (((h & 1) ^ ((kl >> 3) & 1)) << 2) + (size_t)(PR * prg) * 4 * 512;   // the wave's first point
 
-  // folded BN of this lane's out-channel: requested now, used by the finisher at the very end (loaded there,
-  // the two values were one more memory round trip on the launch's critical path)
-  const float sc = prm.bnScale[k], bi = prm.bnBias[k];
+  // folded BN of this lane's four out-channels kq*16 + 4h .. + 3 (see the operand swap in compute()): requested
+  // now, used by the finisher at the very end (loaded there, they were one more memory round trip on the critical path)
+  const int k4 = kq * 16 + 4 * h;
+  f32x4 sc4, bi4;
+#pragma unroll
+  for (int r = 0; r < 4; r++) { sc4[r] = prm.bnScale[k4 + r]; bi4[r] = prm.bnBias[k4 + r]; }
 
   f32x4 acc[NPT];
 #pragma unroll
@@ -174,7 +192,10 @@ wino_f2_small_kernel(const SmallParams prm) {
     for (int jj = 0; jj < 4; jj++)
 #pragma unroll
       for (int e = 0; e < NPT; e++)
-        acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e][jj], bfr[e][jj], acc[e], 0, 0, 0);
+        // the filter fragment as the MFMA's A operand, the transformed pixels as its B operand (both are "one value
+        // per lane, index lane & 15, k = lane >> 4": the swap is free): D = C^T, register r of lane (t16, h) is
+        // out-channel kq*16 + 4h + r of tile t16 -- four CONSECUTIVE out-channels per lane, 16-byte output stores
+        acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[e][jj], v[e][jj], acc[e], 0, 0, 0);
   };
   // Two tasks' operands are kept in flight in registers (a one-wave-per-SIMD workgroup may use the
   // whole 512-VGPR file).  The loop is unrolled by two with named buffers and each refill is pinned
@@ -185,6 +206,7 @@ wino_f2_small_kernel(const SmallParams prm) {
   if (t < ntask) load_task(t, d0, b0);
   if (t + stride < ntask) load_task(t + stride, d1, b1);
   __builtin_amdgcn_sched_barrier(0);
+  mark(1);
 #pragma unroll 1
   while (t < ntask) {
     compute(d0, b0);
@@ -199,11 +221,12 @@ wino_f2_small_kernel(const SmallParams prm) {
     t += 2 * stride;
   }
 
-  // ---- the wave's part of A^T m A (C/D layout: col = lane&15 = out-channel, row = 4*(lane>>4)+r = tile).
+  // ---- the wave's part of A^T m A (C/D layout after the operand swap: col = lane&15 = tile, row = 4*(lane>>4)+r =
+  // out-channel 4h + r of the block).
   // Per point row i:  c0(i) = m_i0 + m_i1 + m_i2,  c1(i) = m_i1 - m_i2 - m_i3;  then
   //   Y[0][b] = c_b(0) + c_b(1) + c_b(2),   Y[1][b] = c_b(1) - c_b(2) - c_b(3)
   // of which this wave adds the terms of its rows (selects on the wave-uniform row index: exact, and
-  // an Inf in one part cannot turn another into NaN).  y[r] = the 2x2 pixels (p = 2a + b) of tile row 4h+r.
+  // an Inf in one part cannot turn another into NaN).  y[r] = the 2x2 pixels (p = 2a + b) of this lane's tile, out-channel 4h+r.
   f32x4 y[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -230,6 +253,8 @@ wino_f2_small_kernel(const SmallParams prm) {
       }
     }
   }
+  if (DIAG) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  mark(2);
   // ---- level 1: the workgroup's four partial blocks meet in wave 0 (in wave order)
   if (q > 0) {
 #pragma unroll
@@ -242,6 +267,7 @@ wino_f2_small_kernel(const SmallParams prm) {
 #pragma unroll
     for (int r = 0; r < 4; r++) y[r] += red[ww][r][lane];
 
+  mark(3);
   // ---- level 2: the S workgroups of a block meet through write-through slabs + one ticket per workgroup
   if (S > 1) {
     const int block = tb16 * (K >> 4) + kq;
@@ -251,10 +277,12 @@ wino_f2_small_kernel(const SmallParams prm) {
     for (int r = 0; r < 4; r++)
       slab_store16(y[r], rsrc_slab, (unsigned)((r * 64 + lane) * 16), base + (unsigned)split * SMALL_SLAB_BYTES);
     wait_vmem_all();   // the write-through stores have left ...
+    mark(4);
     unsigned old = 0;
     if (lane == 0)     // ... before the ticket
       old = __hip_atomic_fetch_add(prm.tickets + block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     old = __builtin_amdgcn_readfirstlane(old);
+    mark(5);
     if (old != (unsigned)(S - 1)) {
       // a counter that was not zero when the launch began (an aborted launch before this one): say so
       if (old >= (unsigned)S && lane == 0) __hip_atomic_store(prm.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -275,6 +303,7 @@ wino_f2_small_kernel(const SmallParams prm) {
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) y[r] = part[0][r];
+    if (DIAG) { wait_vmem_all(); mark(6); }
 #pragma unroll
     for (int s = 1; s < SMALL_MAX_SPLIT; s++) {
       if (s < S) {
@@ -284,44 +313,51 @@ wino_f2_small_kernel(const SmallParams prm) {
     }
   }
 
-  // ---- finalize: BN + ReLU + store (and the block's share of the zero ring)
+  // ---- finalize: BN + ReLU + store (and the block's share of the zero ring).  One tile and four consecutive
+  // out-channels per lane: every store is 16 bytes, the four lane groups of a tile cover 64 contiguous bytes.
+  // (Round 3's first cut held one out-channel of four tiles per lane: 16 four-byte stores and their drain were
+  // 1.6 us of the finisher's 8.8; tools/small_timeline.)
   float* __restrict__ out = prm.out;
   const int relu = prm.relu;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int gt = tb16 * 16 + 4 * h + r;
-    if (gt >= totalTiles) continue;
+  const int gt = tb16 * 16 + t16;
+  if (gt < totalTiles) {
     const TileCoord tc = decode_tile(gt);
-    float* o = out + (size_t)tc.n * WINO_HW * WINO_HW * K + k;
+    float* o = out + (size_t)tc.n * WINO_HW * WINO_HW * K + k4;
     const int oy = 1 + 2 * tc.ty, ox = 1 + 2 * tc.tx;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      float val = sc * y[r][p] + bi;
-      if (relu) val = fmaxf(val, 0.f);
-      o[(size_t)((oy + (p >> 1)) * WINO_HW + ox + (p & 1)) * K] = val;
+      f32x4 val = {y[0][p], y[1][p], y[2][p], y[3][p]};
+      val = sc4 * val + bi4;
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) val[r] = fmaxf(val[r], 0.f);
+      }
+      *(f32x4*)(o + (size_t)((oy + (p >> 1)) * WINO_HW + ox + (p & 1)) * K) = val;
     }
     // zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:163,243)
     if (tc.ty == 0) {
-      o[(size_t)(ox)*K] = 0.f;
-      o[(size_t)(ox + 1) * K] = 0.f;
-      if (tc.tx == 0) o[0] = 0.f;
-      if (tc.tx == 6) o[(size_t)15 * K] = 0.f;
+      *(f32x4*)(o + (size_t)(ox)*K) = zero4;
+      *(f32x4*)(o + (size_t)(ox + 1) * K) = zero4;
+      if (tc.tx == 0) *(f32x4*)(o) = zero4;
+      if (tc.tx == 6) *(f32x4*)(o + (size_t)15 * K) = zero4;
     }
     if (tc.ty == 6) {
-      o[(size_t)(15 * WINO_HW + ox) * K] = 0.f;
-      o[(size_t)(15 * WINO_HW + ox + 1) * K] = 0.f;
-      if (tc.tx == 0) o[(size_t)(15 * WINO_HW) * K] = 0.f;
-      if (tc.tx == 6) o[(size_t)(15 * WINO_HW + 15) * K] = 0.f;
+      *(f32x4*)(o + (size_t)(15 * WINO_HW + ox) * K) = zero4;
+      *(f32x4*)(o + (size_t)(15 * WINO_HW + ox + 1) * K) = zero4;
+      if (tc.tx == 0) *(f32x4*)(o + (size_t)(15 * WINO_HW) * K) = zero4;
+      if (tc.tx == 6) *(f32x4*)(o + (size_t)(15 * WINO_HW + 15) * K) = zero4;
     }
     if (tc.tx == 0) {
-      o[(size_t)(oy * WINO_HW) * K] = 0.f;
-      o[(size_t)((oy + 1) * WINO_HW) * K] = 0.f;
+      *(f32x4*)(o + (size_t)(oy * WINO_HW) * K) = zero4;
+      *(f32x4*)(o + (size_t)((oy + 1) * WINO_HW) * K) = zero4;
     }
     if (tc.tx == 6) {
-      o[(size_t)(oy * WINO_HW + 15) * K] = 0.f;
-      o[(size_t)((oy + 1) * WINO_HW + 15) * K] = 0.f;
+      *(f32x4*)(o + (size_t)(oy * WINO_HW + 15) * K) = zero4;
+      *(f32x4*)(o + (size_t)((oy + 1) * WINO_HW + 15) * K) = zero4;
     }
   }
+  if (DIAG) { wait_vmem_all(); mark(7); }
   clk_exit();
 }
 
