@@ -457,8 +457,8 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
   const long long Tg = Tt / kp, Gp = G / kp;
   const Geo geo = {H + 2, W + 2, tiles, tiles_x, make_fastdiv(tiles), make_fastdiv(tiles_x)};
   const PhaseOrder po = phase_order(Tg / Gp, Tg % Gp, C / BC, Gp);
-  const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tg / Gp), (unsigned)(Tg % Gp), kp,
-                           po.P, po.inv, po.copies, geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, nullptr};
+  const FusedParams prm = {in, U, N, C, K, relu, nTB, (int)(items / (size_t)G), (unsigned)(Tg / Gp), (unsigned)(Tg % Gp), kp, (int)Gp,
+                           po.P, po.inv, po.copies, make_fastdiv((unsigned)kp), make_fastdiv((unsigned)po.P), make_fastdiv((unsigned)po.copies), geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, nullptr};
   // whole items only (no stream-K tail): the kernel variant without the hand-off in its epilogue
   if (Tt == 0) return fixed14 ? launch_fused<false, false>(prm, G, dev, s) : launch_fused<true, false>(prm, G, dev, s);
   return fixed14 ? launch_fused<false, true>(prm, G, dev, s) : launch_fused<true, true>(prm, G, dev, s);
@@ -487,8 +487,8 @@ static int conv3x3_clock_probe(const float* in, const float* U, const float* bnB
   const long long Tg = Tt / kp, Gp = G / kp;
   const Geo geo = {WINO_HW, WINO_HW, WINO_TILES, 7, make_fastdiv(WINO_TILES), make_fastdiv(7)};
   const PhaseOrder po = phase_order(Tg / Gp, Tg % Gp, C / BC, Gp);
-  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / (size_t)G), (unsigned)(Tg / Gp), (unsigned)(Tg % Gp), kp,
-                           po.P, po.inv, po.copies, geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, stamps};
+  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / (size_t)G), (unsigned)(Tg / Gp), (unsigned)(Tg % Gp), kp, (int)Gp,
+                           po.P, po.inv, po.copies, make_fastdiv((unsigned)kp), make_fastdiv((unsigned)po.P), make_fastdiv((unsigned)po.copies), geo, bnBias, bnScale, out, bufs.slabs, bufs.tickets, bufs.err, stamps};
   static std::atomic<unsigned long long> attr_done{0};
   if (!((attr_done.load() >> (dev & 63)) & 1ull)) {
     WINO_HIP(hipFuncSetAttribute((const void*)(wino_f2_fused_kernel<16, false>),

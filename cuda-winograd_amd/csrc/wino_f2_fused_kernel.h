@@ -51,6 +51,20 @@ constexpr int LDS_BYTES = N_RSTAGE * RAW_BYTES + N_USTAGE * U_BYTES;  // 163840 
 constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
 constexpr int PF = 2;                        // filter-fragment prefetch distance (points); 2..6 measured equal
 constexpr int SLAB_BYTES = TB * 4 * KB * 4;  // 65536: pre-BN output of one item (64 tiles x 2x2 px x 64 k)
+#define WINO_STR2(x) #x
+#define WINO_STR(x) WINO_STR2(x)
+#ifndef WINO_EXP_ALIGN
+#define WINO_EXP_ALIGN 0
+#endif
+#ifndef WINO_EXP_NOPS
+#define WINO_EXP_NOPS 0
+#endif
+#ifndef WINO_EXP_NOCLK
+#define WINO_EXP_NOCLK 0
+#endif
+#ifndef WINO_EXP_KP1
+#define WINO_EXP_KP1 0
+#endif
 #ifndef WINO_UNROLL2
 #define WINO_UNROLL2 1   // two copies of the loop body, one per raw-stage parity: the stage is an immediate of the patch reads
 #endif
@@ -156,6 +170,11 @@ __host__ __device__ inline int tail_range_of(int j, int P, int inv, int copies) 
   const int r = j / copies, b = j - r * copies;
   return (inv * r) % P + P * b;
 }
+__device__ __forceinline__ int tail_range_of_fast(int j, int P, int inv, int copies, FastDiv d_P, FastDiv d_copies) {
+  const int r = (int)fastdiv((unsigned)j, d_copies), b = j - r * copies;
+  const int ir = inv * r;
+  return ir - (int)fastdiv((unsigned)ir, d_P) * P + P * b;
+}
 
 // The kernel's only argument.  The fields below the line are used by the epilogue alone: it
 // re-reads them from the kernarg segment each time instead of keeping ~20 scalar registers
@@ -167,7 +186,11 @@ struct FusedParams {
   int ndp;                     // whole-item rounds: items / gridDim.x
   unsigned sk_q, sk_rem;       // tail, per k-group: (items % gridDim.x) / kp * C/8 = sk_q * (gridDim.x / kp) + sk_rem iterations
   int kp;                      // k-groups of the tail: K/64 (gridDim.x a multiple of it) or 1
+  int Gp;                      // gridDim.x / kp: ranges (= positions) per k-group
   int ph_P, ph_inv, ph_copies; // which tail range the j-th position of a group runs (tail_range_of below)
+  FastDiv d_kp, d_P, d_copies; // the three divisors as multipliers: a runtime integer division is ~40 instructions on
+                               // this machine, and the first cut of the k-groups paid five of them in the prologue and
+                               // five in every epilogue (+0.7 us on a 40 us launch)
   Geo geo;                     // feature-map geometry (read by the GEN = true build only)
   // ---- epilogue only ----
   const float* bnBias;
@@ -216,12 +239,12 @@ wino_f2_fused_kernel(const FusedParams prm) {
       prm.dbg[(size_t)lg * 8 + 4] = __builtin_amdgcn_s_memtime();
     }
   }
-  if (ABLATE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (ABLATE == 0 && !WINO_EXP_NOCLK && blockIdx.x == 0 && threadIdx.x == 0) {
     wino_clk_slot_3x3[0] = __builtin_amdgcn_s_memtime();
     wino_clk_slot_3x3[1] = __builtin_amdgcn_s_memrealtime();
   }
   auto clk_exit = [&]() {
-    if (ABLATE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (ABLATE == 0 && !WINO_EXP_NOCLK && blockIdx.x == 0 && threadIdx.x == 0) {
       wino_clk_slot_3x3[2] = __builtin_amdgcn_s_memtime();
       wino_clk_slot_3x3[3] = __builtin_amdgcn_s_memrealtime();
     }
@@ -235,9 +258,9 @@ wino_f2_fused_kernel(const FusedParams prm) {
   // different channel phases, every one of them fetched the patches for itself: HBM-side fetch 164 MB per launch
   // at the reference's 256 channels, N = 128, against 38 MB compulsory.)  kp = 1 is that old scheme.
   const int tail_item0 = ndp * G;
-  const int kpg = prm.kp;
-  const int lpos = __builtin_amdgcn_readfirstlane(kpg > 1 ? lg / kpg : lg), grp = lg - lpos * kpg, Gp = kpg > 1 ? G / kpg : G;
-  const int lp = __builtin_amdgcn_readfirstlane(tail_range_of(lpos, prm.ph_P, prm.ph_inv, prm.ph_copies));   // the group's tail range this workgroup runs
+  const int kpg = prm.kp, Gp = prm.Gp;
+  const int lpos = __builtin_amdgcn_readfirstlane((int)fastdiv((unsigned)lg, prm.d_kp)), grp = lg - lpos * kpg;
+  const int lp = __builtin_amdgcn_readfirstlane(tail_range_of_fast(lpos, prm.ph_P, prm.ph_inv, prm.ph_copies, prm.d_P, prm.d_copies));   // the group's tail range this workgroup runs
   const unsigned t_begin = __builtin_amdgcn_readfirstlane(sk_start(lp, sk_q, sk_rem, Gp));
   const int Lt = (int)(__builtin_amdgcn_readfirstlane(sk_start(lp + 1, sk_q, sk_rem, Gp)) - t_begin);   // tail iterations of this workgroup
   const int L = Lt + ndp * nchunks;                                     // all its chunk iterations
@@ -446,7 +469,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
       dma_set_item(lg);
     } else if (++d_chunk == nchunks) {
       d_chunk = 0;
-      dma_set_item(d_tail > 0 ? d_item + kernarg()->kp : d_item + G);   // the next tail item of this k-group / round
+      dma_set_item(d_tail > 0 ? d_item + (WINO_EXP_KP1 ? 1 : kernarg()->kp) : d_item + G);   // the next tail item of this k-group / round
     } else {
       d_soff_raw += (unsigned)(BC * sizeof(float));
       d_soff_u += u_chunk_stride;
@@ -730,9 +753,20 @@ wino_f2_fused_kernel(const FusedParams prm) {
     const int N = kp->N, K = kp->K, relu = kp->relu, KBLK = K >> 6, totalTiles = N * (GEN ? (int)geo.tiles : WINO_TILES);
     const unsigned sk_q = kp->sk_q, sk_rem = kp->sk_rem;
     const int tail_item0 = kp->ndp * G;
-    const int kpg = kp->kp;   // k-groups of the tail; this workgroup is range lp_e of group grp_e
-    const int lpos_e = kpg > 1 ? lg / kpg : lg, grp_e = lg - lpos_e * kpg, Gp = kpg > 1 ? G / kpg : G;
-    const int lp_e = tail_range_of(lpos_e, kp->ph_P, kp->ph_inv, kp->ph_copies);   // slab slots are numbered by (tail range, group)
+    // k-groups of the tail: this workgroup is range lp_e of group grp_e (slab slots are numbered by (tail range,
+    // group)); worked out only by the partial-segment paths below, with multipliers instead of divisions
+    struct TailPos { int kpg, Gp, lp, grp; FastDiv d_kp; };
+    auto tail_pos = [&]() {
+      TailPos t;
+      t.kpg = kp->kp; t.Gp = kp->Gp;
+      t.d_kp.m = kp->d_kp.m; t.d_kp.l = kp->d_kp.l;
+      FastDiv dP, dC;
+      dP.m = kp->d_P.m; dP.l = kp->d_P.l; dC.m = kp->d_copies.m; dC.l = kp->d_copies.l;
+      const int lpos_e = (int)fastdiv((unsigned)lg, t.d_kp);
+      t.grp = lg - lpos_e * t.kpg;
+      t.lp = tail_range_of_fast(lpos_e, kp->ph_P, kp->ph_inv, kp->ph_copies, dP, dC);
+      return t;
+    };
     const float* bnBias = kp->bnBias;
     const float* bnScale = kp->bnScale;
     unsigned* tickets = kp->tickets;
@@ -840,7 +874,8 @@ wino_f2_fused_kernel(const FusedParams prm) {
     } else if (!(ABLATE & 1024)) {
       // slab slot: 2l for the segment that continues an item (head of l's range), 2l+1 for the
       // one that starts an item
-      const unsigned my_slot = 2u * (unsigned)(lp_e * kpg + grp_e) + ((seg_kind & 2) ? 1u : 0u);
+      const TailPos tp = tail_pos();
+      const unsigned my_slot = 2u * (unsigned)(tp.lp * tp.kpg + tp.grp) + ((seg_kind & 2) ? 1u : 0u);
 #pragma unroll
       for (int q = 0; q < 8; q++)
         slab_store16(y[q >> 1][q & 1], rsrc_slab, slab_voff + q * 1024, my_slot * SLAB_BYTES);
@@ -878,8 +913,10 @@ wino_f2_fused_kernel(const FusedParams prm) {
       if (!(j == 0 && whole)) {
         // which logical workgroups share `item`: walk outwards from lg.  With more workgroups
         // than iterations some own nothing; they are not segments.
-        const unsigned x0 = (unsigned)((item - tail_item0) / kpg) * (unsigned)nchunks, x1 = x0 + nchunks - 1;   // the group's tail space
-        int gA = lp_e, gB = lp_e;
+        const TailPos tp = tail_pos();
+        const int kpg = tp.kpg, Gp = tp.Gp, grp_e = tp.grp;
+        const unsigned x0 = fastdiv((unsigned)(item - tail_item0), tp.d_kp) * (unsigned)nchunks, x1 = x0 + nchunks - 1;   // the group's tail space
+        int gA = tp.lp, gB = tp.lp;
         while (sk_start(gA, sk_q, sk_rem, Gp) > x0) gA--;
         while (gB + 1 < Gp && sk_start(gB + 1, sk_q, sk_rem, Gp) <= x1) gB++;
         int nseg = 0;
@@ -1020,6 +1057,12 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #if WINO_UNROLL2
       {
         int k = n;
+#if WINO_EXP_ALIGN
+        asm volatile(".p2align " WINO_STR(WINO_EXP_ALIGN));
+#endif
+#if WINO_EXP_NOPS
+        asm volatile(".rept " WINO_STR(WINO_EXP_NOPS) "\n\ts_nop 0\n\t.endr");
+#endif
 #pragma unroll 1
         for (;;) {
           if (!(it & 1)) {
@@ -1054,7 +1097,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
         c_item_vg = lg;
         c_tail_vg = 0;
       } else {
-        c_item_vg += c_tail > 0 ? kernarg()->kp : G;
+        c_item_vg += c_tail > 0 ? (WINO_EXP_KP1 ? 1 : kernarg()->kp) : G;
       }
       asm volatile("" : "+v"(c_item_vg), "+v"(c_tail_vg));
     }

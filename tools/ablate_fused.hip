@@ -31,7 +31,22 @@ float run(const float* in, const float* U, const float* b, const float* s, float
   const int grid = grid_for(N, K);
   CK(hipMemset(g_tickets, 0, 65536 * 4));   // ablated variants may leave tickets behind
   const unsigned items = (unsigned)nTB * (K / KB), Tt = (items % grid) * (C / 8);
-  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / grid), Tt / grid, Tt % grid, 1, 1, 0, (int)grid, Geo{}, b, s, out, g_slabs, g_tickets, g_err, g_dbg};
+  // the library's tail placement (wino_f2_fused.hip: tail_groups, phase_order); WINO_TOOL_KP=0 gives round 2's scheme
+  const char* kpenv = getenv("WINO_TOOL_KP");
+  const int kblk = K / KB, kp = (kpenv && kpenv[0] == '0') || kblk <= 1 || grid % kblk ? 1 : kblk;
+  const unsigned Tg = Tt / kp, Gp = grid / kp, q = Tg / Gp, rem = Tg % Gp;
+  int P = 1, inv = 0, copies = (int)Gp;
+  if (!(kpenv && kpenv[0] == '0') && rem == 0 && q > 0) {
+    unsigned a = q % (C / 8), bb = C / 8;
+    while (a) { const unsigned t = bb % a; bb = a; a = t; }
+    const unsigned g = bb, PP = (C / 8) / g;
+    if (PP > 1 && Gp % PP == 0) {
+      const unsigned qq = (q / g) % PP;
+      for (unsigned x = 1; x < PP; x++)
+        if ((qq * x) % PP == 1) { P = (int)PP; inv = (int)x; copies = (int)(Gp / PP); break; }
+    }
+  }
+  const FusedParams prm = {in, U, N, C, K, 1, nTB, (int)(items / grid), q, rem, kp, (int)Gp, P, inv, copies, wino::make_fastdiv((unsigned)kp), wino::make_fastdiv((unsigned)P), wino::make_fastdiv((unsigned)copies), Geo{}, b, s, out, g_slabs, g_tickets, g_err, g_dbg};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; i++)
