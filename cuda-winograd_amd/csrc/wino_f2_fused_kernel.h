@@ -51,20 +51,6 @@ constexpr int LDS_BYTES = N_RSTAGE * RAW_BYTES + N_USTAGE * U_BYTES;  // 163840 
 constexpr int U_CHUNK_FLOATS = 16 * KB * BC; // 8192 floats per (c-chunk, k-block)
 constexpr int PF = 2;                        // filter-fragment prefetch distance (points); 2..6 measured equal
 constexpr int SLAB_BYTES = TB * 4 * KB * 4;  // 65536: pre-BN output of one item (64 tiles x 2x2 px x 64 k)
-#define WINO_STR2(x) #x
-#define WINO_STR(x) WINO_STR2(x)
-#ifndef WINO_EXP_ALIGN
-#define WINO_EXP_ALIGN 0
-#endif
-#ifndef WINO_EXP_NOPS
-#define WINO_EXP_NOPS 0
-#endif
-#ifndef WINO_EXP_NOCLK
-#define WINO_EXP_NOCLK 0
-#endif
-#ifndef WINO_EXP_KP1
-#define WINO_EXP_KP1 0
-#endif
 #ifndef WINO_UNROLL2
 #define WINO_UNROLL2 1   // two copies of the loop body, one per raw-stage parity: the stage is an immediate of the patch reads
 #endif
@@ -239,12 +225,12 @@ wino_f2_fused_kernel(const FusedParams prm) {
       prm.dbg[(size_t)lg * 8 + 4] = __builtin_amdgcn_s_memtime();
     }
   }
-  if (ABLATE == 0 && !WINO_EXP_NOCLK && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (ABLATE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     wino_clk_slot_3x3[0] = __builtin_amdgcn_s_memtime();
     wino_clk_slot_3x3[1] = __builtin_amdgcn_s_memrealtime();
   }
   auto clk_exit = [&]() {
-    if (ABLATE == 0 && !WINO_EXP_NOCLK && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (ABLATE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
       wino_clk_slot_3x3[2] = __builtin_amdgcn_s_memtime();
       wino_clk_slot_3x3[3] = __builtin_amdgcn_s_memrealtime();
     }
@@ -469,7 +455,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
       dma_set_item(lg);
     } else if (++d_chunk == nchunks) {
       d_chunk = 0;
-      dma_set_item(d_tail > 0 ? d_item + (WINO_EXP_KP1 ? 1 : kernarg()->kp) : d_item + G);   // the next tail item of this k-group / round
+      dma_set_item(d_tail > 0 ? d_item + kernarg()->kp : d_item + G);   // the next tail item of this k-group / round
     } else {
       d_soff_raw += (unsigned)(BC * sizeof(float));
       d_soff_u += u_chunk_stride;
@@ -1057,12 +1043,6 @@ wino_f2_fused_kernel(const FusedParams prm) {
 #if WINO_UNROLL2
       {
         int k = n;
-#if WINO_EXP_ALIGN
-        asm volatile(".p2align " WINO_STR(WINO_EXP_ALIGN));
-#endif
-#if WINO_EXP_NOPS
-        asm volatile(".rept " WINO_STR(WINO_EXP_NOPS) "\n\ts_nop 0\n\t.endr");
-#endif
 #pragma unroll 1
         for (;;) {
           if (!(it & 1)) {
@@ -1097,7 +1077,7 @@ wino_f2_fused_kernel(const FusedParams prm) {
         c_item_vg = lg;
         c_tail_vg = 0;
       } else {
-        c_item_vg += c_tail > 0 ? (WINO_EXP_KP1 ? 1 : kernarg()->kp) : G;
+        c_item_vg += c_tail > 0 ? kernarg()->kp : G;
       }
       asm volatile("" : "+v"(c_item_vg), "+v"(c_tail_vg));
     }
