@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "wino_driver_cpu_baseline", "wino_last_status_name", "wino_debug_reload_knobs",
     "wino_residual_block_prepare", "wino_residual_block_prepare_hw", "wino_diag_conv3x3_clock",
     "wino_debug_tickets_in_use", "wino_stream_check", "wino_stream_reset_scratch", "wino_debug_poison_ticket",
-    "wino_diag_last_clock", "wino_conv3x3_small_plan", "wino_conv1x1_small_plan", "wino_conv3x3_plan_groups",
+    "wino_diag_last_clock", "wino_conv3x3_small_plan", "wino_conv1x1_small_plan", "wino_conv3x3_plan_groups", "wino_conv1x1_small_plan2",
     # reference entry points + helpers (Kernel*.h, util.h)
     "kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in",
     "kernel_256_1_out", "get_parameter", "transpose", "getTimeMicroseconds64", "output_checker",
@@ -129,6 +129,7 @@ def lib() -> ctypes.CDLL:
     L.wino_diag_last_clock.argtypes = [c_int, c_void_p, POINTER(ctypes.c_ulonglong)]
     L.wino_conv3x3_small_plan.argtypes = [c_int] * 6 + [POINTER(c_int)] * 4
     L.wino_conv1x1_small_plan.argtypes = [c_long, c_int, c_int, c_int] + [POINTER(c_int)] * 3
+    L.wino_conv1x1_small_plan2.argtypes = [c_long, c_int, c_int, c_int] + [POINTER(c_int)] * 5
     L.wino_conv3x3_plan_groups.argtypes = [c_int] * 6 + [POINTER(c_int)] * 4
     for name in ("kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out",
                  "kernel_256_1_in", "kernel_256_1_out"):
@@ -202,6 +203,13 @@ def small_plan_1x1(M: int, Cin: int, Kout: int, cus: int = 256):
     """(use, k_split, workgroups) of the 1x1 latency form for a plain layer of this shape (host-side)."""
     v = [c_int(0) for _ in range(3)]
     _check(lib().wino_conv1x1_small_plan(M, Cin, Kout, cus, *[ctypes.byref(x) for x in v]), "wino_conv1x1_small_plan")
+    return tuple(int(x.value) for x in v)
+
+
+def small_plan_1x1_full(M: int, Cin: int, Kout: int, cus: int = 256):
+    """(use, k_split, row_tiles, col_tiles, workgroups) of the 1x1 latency form (host-side)."""
+    v = [c_int(0) for _ in range(5)]
+    _check(lib().wino_conv1x1_small_plan2(M, Cin, Kout, cus, *[ctypes.byref(x) for x in v]), "wino_conv1x1_small_plan2")
     return tuple(int(x.value) for x in v)
 
 

@@ -166,59 +166,85 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_f
   return 0;
 }
 
-// The latency form (conv1x1_small_kernel.h): 16 x 16 output blocks, 4 waves per workgroup, the K loop of a
-// block split over KS of them.  For plain layers (no padded operand, no residual) with few pixel rows.
-// Every block pulls its own operands (16 rows of A, 16 columns of B: 128 Cin bytes) through its CU's vector
-// memory path, so the form is bound by bytes and wins while they are few: measured kernel times
-// (profiles/r3: 1 .. 16 images of the four reference layers, KS = 1 / 2 / 4) follow
-//     T = 3.5 us + blocks x 128 Cin bytes / 11 TB/s
-// to about 10 %; the tiled kernel's time comes from sk1_grid's model.  The cheaper prediction wins (M = 196:
-// 1024->256 5.2 us against 19.2, 512->128 4.0 / 10.9, 128->512 3.9 / 6.7, 256->1024 5.7 / 14.6; the tiled
-// kernel takes over at 6-8 images of the 1024->256 and 256->1024 layers, 6 of 128->512, 16 of 512->128).
-// KS: while the coarsest grid (KS = 1: 16 rows x 64 columns per workgroup) leaves CUs idle, the largest of
-// 4 / 2 / 1 whose grid still fits them; beyond one round, the finest split that keeps 128 channels per wave
-// (shorter K loops are all overhead: 256->1024 at 4 images 12.9 us with KS = 2, 18.4 with 4; more, smaller
-// workgroups even out the CUs: 1024->256 at 6 images 25.7 / 21.2 / 19.3 us for KS = 1 / 2 / 4).
-// WINO_1X1_ALGO=big|small and WINO_1X1_SMALL_KS override.
+// The latency form (conv1x1_small_kernel.h): blocks of (16 RT) x (16 CT) outputs held by one wave, 4 waves per
+// workgroup, a block's K loop split over KS of them.  For plain layers (no padded operand, no residual) with few
+// pixel rows.  Every wave pulls its own operands through its CU's vector memory path and that path bounds the form.
+// Per workgroup (its 4 / KS blocks sit side by side): A = (4 / KS) * RT * 16 * Cin * 4 bytes of pixel rows (shared by
+// every column group, i.e. by all XCDs: fabric-side traffic), B = (4 / KS) * CT * 16 * Cin * 4 bytes of filter columns
+// (one XCD per column group: L2 hits).  Kernel times of every legal form at 1 .. 24 images of the four reference layers
+// (profiles/r3/latency_explore_1x1_forms.json, 330 points) fit
+//     T = 1.56 us + depth * (0.0289 us/KB * A + 0.0270 us/KB * B + 0.20 us),   depth = ceil(workgroups / CUs)
+// to 13 % on average; it underestimates launches several workgroups deep, so those must beat the tiled kernel's own
+// launch model (sk1_grid) by 20 %, one-deep launches just beat it.  Against the measured best of both kernels the rule
+// loses 3 % on average (at most 8 %) over those points.  M = 196: 1024->256 5.4 us against the tiled kernel's 19.3,
+// 512->128 3.8 / 10.5, 128->512 3.4 / 6.7, 256->1024 5.2 / 14.4; 8 images: 17.0 / 22.2, 6.8 / 12.0, 6.9 / 8.0, 18.5 / 20.0
+// (32 x 32 blocks: half the operand bytes per FLOP of 16 x 16).  WINO_1X1_ALGO=big|small and WINO_1X1_SMALL_KS / _RT /
+// _CT override.
 struct Small1Plan {
   bool use;
-  int ks;
+  int ks, rt, ct;
   long long wgs;
+  double t_us;
 };
+static bool small1_legal(int Cin, int Kout, int ks, int rt, int ct) {
+  (void)rt;
+  return Cin % (16 * ks) == 0 && Kout % ((4 / ks) * ct * 16) == 0;
+}
+static double small1_time(long M, int Cin, int Kout, int cus, int ks, int rt, int ct, long long* wgs) {
+  const long long rows = (M + 16 * rt - 1) / (16 * rt), cols = Kout / ((4 / ks) * ct * 16);
+  *wgs = rows * cols;
+  const double a_kb = (double)(4 / ks) * rt * 16.0 * Cin * 4.0 / 1e3, b_kb = (double)(4 / ks) * ct * 16.0 * Cin * 4.0 / 1e3;
+  const long long deep = (*wgs + cus - 1) / cus;
+  return 1.56 + (double)deep * (0.0289 * a_kb + 0.0270 * b_kb + 0.20);
+}
 static Small1Plan small1_plan(long M, int Cin, int Kout, int flags, int batch, int cus) {
-  Small1Plan pl = {false, 1, 0};
+  Small1Plan pl = {false, 1, 1, 1, 0, 0.0};
   if (batch != 1 || (flags & ~WINO_RELU) != 0 || M < 1) return pl;
   const Knobs kn = knobs();
-  const long long rb = (M + 15) / 16;
-  const long long wg1 = rb * (Kout / 64);
-  if (rb > 65535) return pl;   // (gridDim.y)
+  double best = 1e30;
+  for (int rt = 1; rt <= 2; rt++)
+    for (int ct = 1; ct <= 2; ct++)
+      for (int ks = 4; ks >= 1; ks >>= 1) {
+        if (!small1_legal(Cin, Kout, ks, rt, ct)) continue;
+        if (Cin / ks < 64 && ks > 1) continue;            // shorter K loops per wave are all overhead
+        if ((kn.small_ks == 1 || kn.small_ks == 2 || kn.small_ks == 4) && ks != kn.small_ks) continue;
+        if ((kn.small_rt == 1 || kn.small_rt == 2) && rt != kn.small_rt) continue;
+        if ((kn.small_ct == 1 || kn.small_ct == 2) && ct != kn.small_ct) continue;
+        long long wgs = 0;
+        const double t = small1_time(M, Cin, Kout, cus, ks, rt, ct, &wgs);
+        const long long rows = (M + 16 * rt - 1) / (16 * rt);
+        if (rows > 65535) continue;                        // gridDim.y
+        if (t < best) { best = t; pl.ks = ks; pl.rt = rt; pl.ct = ct; pl.wgs = wgs; pl.t_us = t; }
+      }
+  if (best > 1e29) return pl;
   {
-    const double t_small = 3.5 + (double)rb * (Kout / 16) * 128.0 * Cin / 11.0e6;
     double t_big = 0.0;
     const bool four = four_waves(Cin, Kout);
     const int bn = four ? 64 : 128;
     (void)sk1_grid(((M + BM - 1) / BM) * (long long)(Kout / bn), Cin / 32, cus, Kout / bn, four, &t_big);
-    pl.use = t_small < t_big;
+    pl.use = best < (pl.wgs > cus ? 0.8 : 1.0) * t_big;
   }
   if (kn.sk_1x1 != -1 || kn.sk_1x1_grid != 0) pl.use = false;   // a developer is forcing a form of the tiled kernel
   if (kn.algo_1x1 == 1) pl.use = false;
   if (kn.algo_1x1 == 2) pl.use = true;
-  if (!pl.use) return pl;
-  pl.ks = 1;
-  for (int ks = 4; ks > 1; ks >>= 1) {
-    if (Cin % (16 * ks) != 0) continue;
-    if (wg1 <= cus ? wg1 * ks <= cus : Cin / ks >= 128) { pl.ks = ks; break; }
-  }
-  if ((kn.small_ks == 1 || kn.small_ks == 2 || kn.small_ks == 4) && Cin % (16 * kn.small_ks) == 0) pl.ks = kn.small_ks;
-  pl.wgs = wg1 * pl.ks;
   return pl;
+}
+template <int RT, int CT>
+static void launch_1x1_small_ks(int ks, dim3 grid, hipStream_t s, const float* A, const float* B, const float* bnBias,
+                                const float* bnScale, float* C, long M, int Cin, int Kout, int relu) {
+  const dim3 block(256);
+  if (ks == 4) hipLaunchKernelGGL((conv1x1_small_kernel<4, RT, CT>), grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  else if (ks == 2) hipLaunchKernelGGL((conv1x1_small_kernel<2, RT, CT>), grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  else hipLaunchKernelGGL((conv1x1_small_kernel<1, RT, CT>), grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
 }
 static int launch_1x1_small(const Small1Plan& pl, const float* A, const float* B, const float* bnBias,
                             const float* bnScale, float* C, long M, int Cin, int Kout, int relu, hipStream_t s) {
-  const dim3 grid((unsigned)(Kout / 64 * pl.ks), (unsigned)((M + 15) / 16)), block(256);   // x = column group: see the kernel
-  if (pl.ks == 4) hipLaunchKernelGGL(conv1x1_small_kernel<4>, grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
-  else if (pl.ks == 2) hipLaunchKernelGGL(conv1x1_small_kernel<2>, grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
-  else hipLaunchKernelGGL(conv1x1_small_kernel<1>, grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  // x = column group, y = row block: see the kernel
+  const dim3 grid((unsigned)(Kout / ((4 / pl.ks) * pl.ct * 16)), (unsigned)((M + 16 * pl.rt - 1) / (16 * pl.rt)));
+  if (pl.rt == 2 && pl.ct == 2) launch_1x1_small_ks<2, 2>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  else if (pl.rt == 2) launch_1x1_small_ks<2, 1>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  else if (pl.ct == 2) launch_1x1_small_ks<1, 2>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  else launch_1x1_small_ks<1, 1>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
   return launch_status("conv1x1_small_kernel");
 }
 
@@ -379,7 +405,13 @@ int wino_conv1x1_plan(long M, int Cin, int Kout, int cus, int* grid, int* row_ti
 // Host-side only: does a PLAIN layer of this shape take the latency form (conv1x1_small_kernel.h) on a device
 // with `cus` CUs: *use, the K-split inside a workgroup and the number of workgroups.
 int wino_conv1x1_small_plan(long M, int Cin, int Kout, int cus, int* use, int* k_split, int* workgroups) {
-  if (!use || !k_split || !workgroups || cus < 1) { set_error("bad argument"); return WINO_E_ARG; }
+  int rt = 0, ct = 0;
+  return wino_conv1x1_small_plan2(M, Cin, Kout, cus, use, k_split, &rt, &ct, workgroups);
+}
+
+int wino_conv1x1_small_plan2(long M, int Cin, int Kout, int cus, int* use, int* k_split, int* row_tiles, int* col_tiles,
+                             int* workgroups) {
+  if (!use || !k_split || !row_tiles || !col_tiles || !workgroups || cus < 1) { set_error("bad argument"); return WINO_E_ARG; }
   if (M < 1 || bad_1x1_dims(Cin, Kout)) {
     set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% 64 == 0)", M, Cin, Kout);
     return WINO_E_SHAPE;
@@ -387,6 +419,8 @@ int wino_conv1x1_small_plan(long M, int Cin, int Kout, int cus, int* use, int* k
   const Small1Plan pl = small1_plan(M, Cin, Kout, 0, 1, cus);
   *use = pl.use;
   *k_split = pl.ks;
+  *row_tiles = pl.rt;
+  *col_tiles = pl.ct;
   *workgroups = pl.use ? (int)pl.wgs : 0;
   return WINO_OK;
 }

@@ -149,6 +149,8 @@ void read_knobs() {
   const char* algo1 = getenv("WINO_1X1_ALGO");
   k.algo_1x1 = algo1 && !strcmp(algo1, "big") ? 1 : algo1 && !strcmp(algo1, "small") ? 2 : 0;
   k.small_ks = env_num("WINO_1X1_SMALL_KS", 0);
+  k.small_rt = env_num("WINO_1X1_SMALL_RT", 0);
+  k.small_ct = env_num("WINO_1X1_SMALL_CT", 0);
   g_knobs = k;
 }
 }  // namespace

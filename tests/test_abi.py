@@ -321,14 +321,24 @@ def test_latency_plans_at_the_reference_point(pkg, knobs):
             if use and sp > 1:
                 assert 4 * sp <= (C // 16) * (4 // pr) and 1 <= sp <= 8 and pr in (1, 2, 4), (C, N, pr, sp)
                 assert wgs <= 256
-    want = {(1024, 256): (1, 4, 208), (512, 128): (1, 4, 104), (128, 512): (1, 2, 208), (256, 1024): (1, 1, 208)}
+    # (use, K-split, row tiles, column tiles, workgroups) at M = 196
+    want = {(1024, 256): (1, 4, 1, 1, 208), (512, 128): (1, 4, 1, 1, 104), (128, 512): (1, 2, 1, 1, 208),
+            (256, 1024): (1, 4, 2, 2, 224)}
     for (cin, kout), plan in want.items():
-        assert pkg.small_plan_1x1(196, cin, kout, cus=256) == plan, (cin, kout)
-    # where the tiled kernel takes over (images): measured crossovers, profiles/r3
-    for (cin, kout), (last_small, first_big) in {(1024, 256): (6, 8), (512, 128): (12, 20), (128, 512): (4, 8),
-                                                 (256, 1024): (4, 8)}.items():
+        assert pkg.small_plan_1x1_full(196, cin, kout, cus=256) == plan, (cin, kout)
+    # where the tiled kernel takes over (images): measured crossovers, profiles/r3/latency_explore_1x1_forms.json
+    for (cin, kout), (last_small, first_big) in {(1024, 256): (8, 12), (512, 128): (16, 24), (128, 512): (8, 12),
+                                                 (256, 1024): (6, 8)}.items():
         assert pkg.small_plan_1x1(last_small * 196, cin, kout, cus=256)[0] == 1, (cin, kout, last_small)
         assert pkg.small_plan_1x1(first_big * 196, cin, kout, cus=256)[0] == 0, (cin, kout, first_big)
+    # from a few images on a wave holds 2 x 2 MFMA tiles (half the operand bytes per FLOP)
+    assert pkg.small_plan_1x1_full(8 * 196, 1024, 256, cus=256)[2:4] == (2, 2)
+    # every plan is a legal launch: the K-split divides Cin into whole 16-channel super-chunks, the workgroup's
+    # column span divides Kout
+    for cin, kout in ((32, 64), (96, 64), (160, 192), (2048, 64), (64, 448), (1024, 256)):
+        for M in (1, 17, 196, 1000, 5000):
+            use, ks, rt, ct, wgs = pkg.small_plan_1x1_full(M, cin, kout, cus=256)
+            assert cin % (16 * ks) == 0 and kout % ((4 // ks) * ct * 16) == 0 and rt in (1, 2) and ct in (1, 2), (cin, kout, M)
     assert pkg.small_plan_1x1(128 * 196, 1024, 256, cus=256)[0] == 0
     # a developer forcing a form of the tiled kernel gets the tiled kernel
     knobs.set("WINO_1X1_SK", "1")

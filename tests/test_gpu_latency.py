@@ -125,9 +125,9 @@ def test_conv3x3_latency_in_a_graph(pkg, torch_dev):
                                             (196, 256, 1024, False), (1, 32, 64, True), (17, 96, 64, False),
                                             (392, 1024, 256, True), (50, 160, 192, True), (200, 2048, 64, True)])
 def test_one_by_one_latency_forms_agree(M, Cin, Kout, relu, pkg, torch_dev, knobs):
-    """16 x 16 output blocks, the K loop split over KS waves of a workgroup: the forced latency form (whatever
-    KS the policy picks), the forced tiled kernel and the automatic choice must all match an fp64 GEMM, the
-    latency form bit for bit from launch to launch and on NaN-filled outputs (ragged last row block)."""
+    """Blocks of (16 RT) x (16 CT) outputs per wave, the K loop split over KS waves of a workgroup: every legal
+    (RT, CT, KS) form, the forced tiled kernel and the automatic choice must all match an fp64 GEMM, the latency
+    forms bit for bit from launch to launch and on NaN-filled outputs (ragged last row block, ragged K groups)."""
     torch, dev = torch_dev
     g = torch.Generator(device="cpu").manual_seed(M + Cin)
     mk = lambda *s: ((torch.rand(*s, generator=g) - 0.5) * 4).to(dev)
@@ -136,20 +136,36 @@ def test_one_by_one_latency_forms_agree(M, Cin, Kout, relu, pkg, torch_dev, knob
     if relu:
         want = torch.relu(want)
     scale = float(want.abs().max())
-    outs = {}
-    for algo in ("small", "big", None):
-        if algo:
-            knobs.set("WINO_1X1_ALGO", algo)
-        else:
-            knobs.unset("WINO_1X1_ALGO")
+
+    def check(tag):
         out = torch.full((M, Kout), float("nan"), device=dev)
         pkg.conv1x1_bn(A, Bm, b, s, relu, out=out)
-        assert not bool(torch.isnan(out).any()), algo
-        assert float((out.double() - want).abs().max()) < TIGHT * scale, algo
-        for _ in range(3):
-            assert torch.equal(pkg.conv1x1_bn(A, Bm, b, s, relu), out), algo
-        outs[algo] = out
-    assert float((outs["small"] - outs["big"]).abs().max()) < 4e-6 * scale
+        assert not bool(torch.isnan(out).any()), tag
+        assert float((out.double() - want).abs().max()) < TIGHT * scale, tag
+        for _ in range(2):
+            assert torch.equal(pkg.conv1x1_bn(A, Bm, b, s, relu), out), tag
+        return out
+
+    knobs.set("WINO_1X1_ALGO", "big")
+    big = check("big")
+    knobs.set("WINO_1X1_ALGO", "small")
+    forms = 0
+    for rt in (1, 2):
+        for ct in (1, 2):
+            for ks in (1, 2, 4):
+                if Cin % (16 * ks) or Kout % ((4 // ks) * ct * 16) or (Cin // ks < 64 and ks > 1):
+                    continue
+                knobs.set("WINO_1X1_SMALL_KS", ks)
+                knobs.set("WINO_1X1_SMALL_RT", rt)
+                knobs.set("WINO_1X1_SMALL_CT", ct)
+                assert pkg.small_plan_1x1_full(M, Cin, Kout)[:4] == (1, ks, rt, ct)
+                out = check((rt, ct, ks))
+                assert float((out - big).abs().max()) < 4e-6 * scale, (rt, ct, ks)
+                forms += 1
+    assert forms >= 2
+    for k in ("WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SMALL_RT", "WINO_1X1_SMALL_CT"):
+        knobs.unset(k)
+    check("auto")
     assert pkg.tickets_in_use() == 0
 
 

@@ -19,7 +19,8 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "quick"
 
 
 def knob(**kw):
-    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS"):
+    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SMALL_RT",
+              "WINO_1X1_SMALL_CT"):
         os.environ.pop(k, None)
     for k, v in kw.items():
         os.environ[k] = str(v)
@@ -59,13 +60,28 @@ def conv1(Cin, Kout, N, **kw):
     torch.cuda.synchronize()
     knob(**kw)
     tag = " ".join("%s=%s" % (k.replace("WINO_", "").lower(), v) for k, v in kw.items()) or "auto"
-    use, ks, wgs = pkg.small_plan_1x1(N * 196, Cin, Kout)
-    form = "small ks%d" % ks if use else "big"
+    use, ks, rt, ct, wgs = pkg.small_plan_1x1_full(N * 196, Cin, Kout)
+    form = "small %dx%d ks%d %d wgs" % (rt, ct, ks, wgs) if use else "big"
     run("1x1 %d->%d N=%d [%s -> %s]" % (Cin, Kout, N, tag, form), lambda: pkg.conv1x1_bn(A, Bm, b, s, True, out=out))
     knob()
 
 
 small = lambda pr, sp: dict(WINO_3X3_ALGO="small", WINO_SMALL_PR=pr, WINO_SMALL_SPLIT=sp)
+if mode == "explore1":   # the 1x1 latency form: every block shape and K-split against the tiled kernel
+    for Cin, Kout in ((1024, 256), (512, 128), (128, 512), (256, 1024)):
+        for N in (1, 2, 3, 4, 6, 8, 12, 16, 24):
+            conv1(Cin, Kout, N)
+            conv1(Cin, Kout, N, WINO_1X1_ALGO="big")
+            for rt, ct in ((1, 1), (2, 2), (1, 2), (2, 1)):
+                for ks in (4, 2, 1):
+                    if Cin % (16 * ks) or Kout % ((4 // ks) * ct * 16) or (Cin // ks < 64 and ks > 1):
+                        continue
+                    if N >= 12 and (rt, ct) == (1, 1):
+                        continue
+                    conv1(Cin, Kout, N, WINO_1X1_ALGO="small", WINO_1X1_SMALL_KS=ks, WINO_1X1_SMALL_RT=rt, WINO_1X1_SMALL_CT=ct)
+    for c in cases:
+        print(json.dumps(c), flush=True)
+    sys.exit(0)
 if mode == "explore":   # beyond one round of blocks / workgroups: where do the latency forms stop paying?
     for N in (6, 8, 10, 12, 16, 20, 24):
         conv3(128, N, WINO_3X3_ALGO="big")
