@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "wino_residual_block_prepare", "wino_residual_block_prepare_hw", "wino_diag_conv3x3_clock",
     "wino_debug_tickets_in_use", "wino_stream_check", "wino_stream_reset_scratch", "wino_debug_poison_ticket",
     "wino_diag_last_clock", "wino_conv3x3_small_plan", "wino_conv1x1_small_plan", "wino_conv3x3_plan_groups", "wino_conv1x1_small_plan2",
+    "wino_conv3x3_small_plan2",
     # reference entry points + helpers (Kernel*.h, util.h)
     "kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in",
     "kernel_256_1_out", "get_parameter", "transpose", "getTimeMicroseconds64", "output_checker",
@@ -128,6 +129,7 @@ def lib() -> ctypes.CDLL:
     L.wino_debug_poison_ticket.argtypes = [c_void_p, c_long, ctypes.c_uint]
     L.wino_diag_last_clock.argtypes = [c_int, c_void_p, POINTER(ctypes.c_ulonglong)]
     L.wino_conv3x3_small_plan.argtypes = [c_int] * 6 + [POINTER(c_int)] * 4
+    L.wino_conv3x3_small_plan2.argtypes = [c_int] * 6 + [POINTER(c_int)] * 5
     L.wino_conv1x1_small_plan.argtypes = [c_long, c_int, c_int, c_int] + [POINTER(c_int)] * 3
     L.wino_conv1x1_small_plan2.argtypes = [c_long, c_int, c_int, c_int] + [POINTER(c_int)] * 5
     L.wino_conv3x3_plan_groups.argtypes = [c_int] * 6 + [POINTER(c_int)] * 4
@@ -196,6 +198,13 @@ def small_plan_3x3(N: int, C: int, K: int, cus: int = 256, H: int = 14, W: int =
     """(use, point_rows, split, workgroups) of the 3x3 latency kernel for this shape (host-side)."""
     v = [c_int(0) for _ in range(4)]
     _check(lib().wino_conv3x3_small_plan(N, H, W, C, K, cus, *[ctypes.byref(x) for x in v]), "wino_conv3x3_small_plan")
+    return tuple(int(x.value) for x in v)
+
+
+def small_plan_3x3_full(N: int, C: int, K: int, cus: int = 256, H: int = 14, W: int = 14):
+    """(use, point_rows, split, col_tiles, workgroups) of the 3x3 latency kernel (host-side)."""
+    v = [c_int(0) for _ in range(5)]
+    _check(lib().wino_conv3x3_small_plan2(N, H, W, C, K, cus, *[ctypes.byref(x) for x in v]), "wino_conv3x3_small_plan2")
     return tuple(int(x.value) for x in v)
 
 

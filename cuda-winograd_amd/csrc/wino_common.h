@@ -50,6 +50,7 @@ struct Knobs {
                       // item-major list in launch order; 2 / 3 only the groups / only the phase order (A/B measurements)
   int small_split;    // WINO_SMALL_SPLIT: C-split S of the 3x3 latency kernel (0 = policy)
   int small_pr;       // WINO_SMALL_PR: point rows per task of the 3x3 latency kernel, 1 / 2 / 4 (0 = policy)
+  int small3_ct;      // WINO_SMALL_CT: MFMA tiles per wave (block width / 16) of the 3x3 latency kernel, 1 / 2 / 4 (0 = policy)
   int algo_1x1;       // WINO_1X1_ALGO: 0 automatic, 1 "big" (LDS-staged kernel), 2 "small" (latency kernel)
   int small_ks;       // WINO_1X1_SMALL_KS: K-split of the 1x1 latency kernel, 1 / 2 / 4 (0 = policy)
   int small_rt, small_ct;   // WINO_1X1_SMALL_RT / _CT: MFMA row / column tiles per wave, 1 / 2 (0 = policy)

@@ -361,5 +361,263 @@ wino_f2_small_kernel(const SmallParams prm) {
   clk_exit();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same kernel with WIDER blocks per wave, for the batches between the reference's one image and the throughput
+// kernel's range: a wave holds CT MFMA tiles side by side (16 tiles x 16 CT out-channels) of 8 points (PR = 2: two
+// rows of the point grid), so that every pixel fragment -- the expensive operand: a 16-byte load per lane whose 64
+// lanes touch 16 cache lines, against 8 for a filter fragment -- and its B^T d B transform feed CT MFMAs.  Measured
+// per wave-task (4 waves per CU, operands in L2): 0.11 us per pixel load, 0.05 per filter load; a 16 x 16 block costs
+// 16 + 16 loads per 64 MFMAs, a 16 x 32 block 12 + 16, a 16 x 64 block 12 + 32 per 128 -- the form is bound by what
+// a CU's vector memory path takes in, not by the MFMAs (8 passes each).  (Blocks of 32 tiles -- two pixel fragments
+// per filter fragment -- were built and measured too: 30-38 us where these take 21-28, the pixel loads being the
+// dear ones; not kept.)  128 accumulator registers at CT = 4 leave no room for a second operand buffer: the next
+// task's loads are issued PROGRESSIVELY instead -- its pixels as soon as the transform has consumed the current
+// ones, each out-channel block's filter points as soon as that block's MFMAs are done.  Reductions, slabs, tickets
+// and the finalize are the 16 x 16 kernel's, per tile of the block.
+template <int CT>
+__global__ void __launch_bounds__(64 * SMALL_WAVES)
+wino_f2_small2_kernel(const SmallParams prm) {
+  static_assert(CT == 2 || CT == 4, "MFMA tiles per wave");
+  __shared__ f32x4 red[SMALL_WAVES - 1][CT * 4][64];   // post-transform partials of waves 1..3 (48 KB at CT = 4)
+  const float* __restrict__ in = prm.in;
+  const float* __restrict__ Uq = prm.Uq;
+  const int N = prm.N, C = prm.C, K = prm.K;
+  const int lane = threadIdx.x & 63;
+  const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t16 = lane & 15, h = lane >> 4;
+  const int tb16 = blockIdx.y, kqq = blockIdx.x;       // x = out-channel block: the workgroups sharing a filter slice share an XCD
+  const int S = gridDim.z, split = blockIdx.z;
+  const bool clk = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+  if (clk) {
+    wino_clk_slot_3x3[0] = __builtin_amdgcn_s_memtime();
+    wino_clk_slot_3x3[1] = __builtin_amdgcn_s_memrealtime();
+  }
+  auto clk_exit = [&]() {
+    if (clk) {
+      wino_clk_slot_3x3[2] = __builtin_amdgcn_s_memtime();
+      wino_clk_slot_3x3[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
+  const int totalTiles = N * WINO_TILES;
+  const int KBLK = K >> 6;
+  // tasks: t = super-chunk * 2 + row group (point rows 2g, 2g+1); wave gw takes t = gw, gw + 4 S, ... (same g throughout)
+  const int gw = split * SMALL_WAVES + q;
+  const int prg = gw & 1;
+  const int ntask = (C / 16) * 2;
+  const int stride = SMALL_WAVES * S;
+  // patch rows ("slots") of the row group: (d0, d2, d1) / (d2, d1, d3); tmp0 = s0 - s1, tmp1 = s1 + sg * s2
+  const int slot0 = prg ? 2 : 0, slot1 = prg ? 1 : 2, slot2 = prg ? 3 : 1;
+  const float sg = prg ? -1.f : 1.f;
+
+  int g = tb16 * 16 + t16;
+  g = g < totalTiles ? g : totalTiles - 1;
+  const TileCoord tca = decode_tile(g);
+  const float* a_src = in + ((size_t)(tca.n * WINO_HW + 2 * tca.ty) * WINO_HW + 2 * tca.tx) * C + 4 * h;
+  const size_t b_chunk_stride = (size_t)KBLK * U_CHUNK_FLOATS;
+  const float* b_src[CT];
+#pragma unroll
+  for (int c = 0; c < CT; c++) {
+    const int k = (kqq * CT + c) * 16 + t16, kb = k >> 6, kl = k & 63;
+    b_src[c] = Uq + (size_t)(h >> 1) * b_chunk_stride + ((size_t)kb * 16 * 64 + kl) * 8 + (((h & 1) ^ ((kl >> 3) & 1)) << 2) +
+               (size_t)(2 * prg) * 4 * 512;   // the wave's first point
+  }
+  // folded BN of this lane's out-channels (kqq*CT + c)*16 + 4h .. + 3: requested now, used by the finisher
+  f32x4 sc4[CT], bi4[CT];
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      sc4[c][r] = prm.bnScale[(kqq * CT + c) * 16 + 4 * h + r];
+      bi4[c][r] = prm.bnBias[(kqq * CT + c) * 16 + 4 * h + r];
+    }
+
+  f32x4 acc[8][CT];
+#pragma unroll
+  for (int e = 0; e < 8; e++)
+#pragma unroll
+    for (int c = 0; c < CT; c++) acc[e][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 d[12], b[CT][8];
+  auto load_a = [&](int t) {
+    const float* ap = a_src + (t >> 1) * 16;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      d[0 * 4 + j] = *(const f32x4*)(ap + (size_t)(slot0 * WINO_HW + j) * C);
+      d[1 * 4 + j] = *(const f32x4*)(ap + (size_t)(slot1 * WINO_HW + j) * C);
+      d[2 * 4 + j] = *(const f32x4*)(ap + (size_t)(slot2 * WINO_HW + j) * C);
+    }
+  };
+  auto load_b = [&](int t, int c) {
+    const float* bp = b_src[c] + (size_t)(t >> 1) * 2 * b_chunk_stride;
+#pragma unroll
+    for (int e = 0; e < 8; e++) b[c][e] = *(const f32x4*)(bp + e * 512);
+  };
+  int t = gw;
+  if (t < ntask) {
+    load_a(t);
+#pragma unroll
+    for (int c = 0; c < CT; c++) load_b(t, c);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (; t < ntask; t += stride) {
+    const bool more = t + stride < ntask;
+    f32x4 tmp[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      tmp[0 * 4 + j] = d[0 * 4 + j] - d[1 * 4 + j];
+      tmp[1 * 4 + j] = d[1 * 4 + j] + sg * d[2 * 4 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      v[i * 4 + 0] = tmp[i * 4 + 0] - tmp[i * 4 + 2];
+      v[i * 4 + 1] = tmp[i * 4 + 1] + tmp[i * 4 + 2];
+      v[i * 4 + 2] = tmp[i * 4 + 2] - tmp[i * 4 + 1];
+      v[i * 4 + 3] = tmp[i * 4 + 1] - tmp[i * 4 + 3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) load_a(t + stride);            // the pixels of the next task: d is dead from here on
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          // filter fragment = the MFMA's A operand, transformed pixels its B operand: register r of lane (t16, h) is
+          // out-channel 4h + r of tile t16 (see the 16 x 16 kernel)
+          acc[e][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[c][e][jj], v[e][jj], acc[e][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) load_b(t + stride, c);       // ... and this out-channel block's points, behind its MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- the wave's part of A^T m A: y[c][r] = the 2x2 pixels (p = 2a + b) of tile t16, out-channel block c, channel 4h + r
+  f32x4 y[CT][4];
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float cc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const float m0 = acc[i * 4 + 0][c][r], m1 = acc[i * 4 + 1][c][r];
+        const float m2 = acc[i * 4 + 2][c][r], m3 = acc[i * 4 + 3][c][r];
+        cc[i][0] = m0 + m1 + m2;
+        cc[i][1] = m1 - m2 - m3;
+      }
+#pragma unroll
+      for (int bb = 0; bb < 2; bb++) {
+        const float sum = cc[0][bb] + cc[1][bb];
+        y[c][r][bb] = prg ? cc[0][bb] : sum;             // rows (0,1): c0 + c1;  rows (2,3): c2
+        y[c][r][2 + bb] = prg ? -sum : cc[1][bb];        // rows (0,1): c1;       rows (2,3): -(c2 + c3)
+      }
+    }
+  // ---- level 1: the workgroup's four partial blocks meet in wave 0 (in wave order)
+  if (q > 0) {
+#pragma unroll
+    for (int i = 0; i < CT * 4; i++) red[q - 1][i][lane] = y[i >> 2][i & 3];
+  }
+  __syncthreads();
+  if (q > 0) return;
+#pragma unroll
+  for (int ww = 0; ww < SMALL_WAVES - 1; ww++)
+#pragma unroll
+    for (int i = 0; i < CT * 4; i++) y[i >> 2][i & 3] += red[ww][i][lane];
+
+  // ---- level 2: the S workgroups of a block meet through write-through slabs + one ticket per workgroup
+  if (S > 1) {
+    constexpr unsigned SLAB = CT * SMALL_SLAB_BYTES;
+    const int block = tb16 * (int)gridDim.x + kqq;
+    const auto rsrc_slab = make_rsrc(prm.slabs, (unsigned)((size_t)gridDim.x * gridDim.y * S * SLAB));
+    const unsigned base = (unsigned)(block * S) * SLAB;
+#pragma unroll
+    for (int i = 0; i < CT * 4; i++)
+      slab_store16(y[i >> 2][i & 3], rsrc_slab, (unsigned)((i * 64 + lane) * 16), base + (unsigned)split * SLAB);
+    wait_vmem_all();   // the write-through stores have left ...
+    unsigned old = 0;
+    if (lane == 0)     // ... before the ticket
+      old = __hip_atomic_fetch_add(prm.tickets + block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(S - 1)) {
+      if (old >= (unsigned)S && lane == 0) __hip_atomic_store(prm.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      clk_exit();
+      return;          // another workgroup finishes the block
+    }
+    if (lane == 0)     // self-cleaning counter (subtracted, not stored: see the 16 x 16 kernel)
+      __hip_atomic_fetch_sub(prm.tickets + block, (unsigned)S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // all S slabs, added in split order (bitwise reproducible whoever finishes); one tile's 4 registers at a time
+    // keeps 4 S loads in flight
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      f32x4 part[SMALL_MAX_SPLIT][4];
+#pragma unroll
+      for (int s = 0; s < SMALL_MAX_SPLIT; s++) {
+        if (s < S) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            part[s][r] = slab_load16(rsrc_slab, (unsigned)(((c * 4 + r) * 64 + lane) * 16), base + (unsigned)s * SLAB);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) y[c][r] = part[0][r];
+#pragma unroll
+      for (int s = 1; s < SMALL_MAX_SPLIT; s++) {
+        if (s < S) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) y[c][r] += part[s][r];
+        }
+      }
+    }
+  }
+
+  // ---- finalize: BN + ReLU + 16-byte stores (and the tile's share of the zero ring)
+  const int gt = tb16 * 16 + t16;
+  if (gt >= totalTiles) { clk_exit(); return; }
+  float* __restrict__ out = prm.out;
+  const int relu = prm.relu;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const TileCoord tc = decode_tile(gt);
+  const int oy = 1 + 2 * tc.ty, ox = 1 + 2 * tc.tx;
+#pragma unroll
+  for (int c = 0; c < CT; c++) {
+    float* o = out + (size_t)tc.n * WINO_HW * WINO_HW * K + (kqq * CT + c) * 16 + 4 * h;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      f32x4 val = {y[c][0][p], y[c][1][p], y[c][2][p], y[c][3][p]};
+      val = sc4[c] * val + bi4[c];
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) val[r] = fmaxf(val[r], 0.f);
+      }
+      *(f32x4*)(o + (size_t)((oy + (p >> 1)) * WINO_HW + ox + (p & 1)) * K) = val;
+    }
+    // zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:163,243)
+    if (tc.ty == 0) {
+      *(f32x4*)(o + (size_t)(ox)*K) = zero4;
+      *(f32x4*)(o + (size_t)(ox + 1) * K) = zero4;
+      if (tc.tx == 0) *(f32x4*)(o) = zero4;
+      if (tc.tx == 6) *(f32x4*)(o + (size_t)15 * K) = zero4;
+    }
+    if (tc.ty == 6) {
+      *(f32x4*)(o + (size_t)(15 * WINO_HW + ox) * K) = zero4;
+      *(f32x4*)(o + (size_t)(15 * WINO_HW + ox + 1) * K) = zero4;
+      if (tc.tx == 0) *(f32x4*)(o + (size_t)(15 * WINO_HW) * K) = zero4;
+      if (tc.tx == 6) *(f32x4*)(o + (size_t)(15 * WINO_HW + 15) * K) = zero4;
+    }
+    if (tc.tx == 0) {
+      *(f32x4*)(o + (size_t)(oy * WINO_HW) * K) = zero4;
+      *(f32x4*)(o + (size_t)((oy + 1) * WINO_HW) * K) = zero4;
+    }
+    if (tc.tx == 6) {
+      *(f32x4*)(o + (size_t)(oy * WINO_HW + 15) * K) = zero4;
+      *(f32x4*)(o + (size_t)((oy + 1) * WINO_HW + 15) * K) = zero4;
+    }
+  }
+  clk_exit();
+}
+
 }  // namespace fused
 }  // namespace wino

@@ -49,7 +49,7 @@ extern "C" {
  * wino_driver_set_gpu_alias, wino_driver_set_stdout_compat, wino_driver_cpu_baseline,
  * wino_diag_conv3x3_clock, wino_debug_tickets_in_use, wino_stream_check, wino_stream_reset_scratch,
  * wino_debug_poison_ticket, wino_diag_last_clock, wino_conv3x3_small_plan, wino_conv1x1_small_plan,
- * wino_conv3x3_plan_groups, wino_conv1x1_small_plan2,
+ * wino_conv3x3_plan_groups, wino_conv1x1_small_plan2, wino_conv3x3_small_plan2,
  * WINO_E_STATE.  The library-owned stream-K scratch is never freed or moved while its
  * stream lives (it used to be reallocated when a larger shape arrived). */
 #define WINO_ABI_VERSION 1
@@ -178,6 +178,11 @@ int wino_conv3x3_plan_groups(int N, int H, int W, int C, int K, int cus, int* gr
  * library-owned slabs + tickets when > 1); *workgroups = blocks x split. */
 int wino_conv3x3_small_plan(int N, int H, int W, int C, int K, int cus, int* use, int* point_rows, int* split,
                             int* workgroups);
+/* The same with the block width: a wave holds *col_tiles MFMA tiles side by side (a block = 16 tiles x
+ * 16 col_tiles out-channels; 1 at the reference's N = 1, 2 or 4 for the batches between that and the
+ * throughput kernel's range, two point rows per task then). */
+int wino_conv3x3_small_plan2(int N, int H, int W, int C, int K, int cus, int* use, int* point_rows, int* split,
+                             int* col_tiles, int* workgroups);
 
 /* ---- F(4x4,3x3) compatibility path ------------------------------
  * The reference's own three-stage arithmetic on its own pre-transformed weight file, consumed as is:

@@ -303,21 +303,27 @@ def test_latency_plans_at_the_reference_point(pkg, knobs):
     on (nearly) every CU: the 3x3 layers as 64 blocks x 4 C-splits (256 channels) / 32 blocks x 8 with one
     point row per task (128 channels), the 1x1 layers as 16 x 16 blocks with the K-split that fills the CUs;
     and hand over to the throughput / tiled kernels where the measurements (profiles/r3) say so."""
-    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SK",
+    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_SMALL_CT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SK",
               "WINO_1X1_SK_GRID"):
         knobs.unset(k)
     assert pkg.small_plan_3x3(1, 256, 256, cus=256) == (1, 4, 4, 256)
     assert pkg.small_plan_3x3(1, 128, 128, cus=256) == (1, 1, 8, 256)
-    assert pkg.small_plan_3x3(2, 256, 256, cus=256)[:3] == (1, 4, 2)
-    assert pkg.small_plan_3x3(5, 256, 256, cus=256)[:3] == (1, 4, 1)       # 256 blocks: one round, no split
-    assert pkg.small_plan_3x3(6, 256, 256, cus=256)[0] == 0                # a second round: the throughput kernel
-    assert pkg.small_plan_3x3(10, 128, 128, cus=256)[0] == 1 and pkg.small_plan_3x3(11, 128, 128, cus=256)[0] == 0
+    # beyond one image: (use, point rows, C-split, block width / 16, workgroups) -- wider blocks as the batch grows
+    assert pkg.small_plan_3x3_full(2, 256, 256, cus=256) == (1, 2, 4, 2, 224)
+    assert pkg.small_plan_3x3_full(5, 256, 256, cus=256) == (1, 2, 2, 2, 256)
+    assert pkg.small_plan_3x3_full(8, 256, 256, cus=256) == (1, 2, 1, 2, 200)
+    assert pkg.small_plan_3x3_full(16, 256, 256, cus=256) == (1, 2, 1, 4, 196)
+    assert pkg.small_plan_3x3_full(20, 256, 256, cus=256)[:4] == (1, 2, 1, 4)
+    assert pkg.small_plan_3x3(21, 256, 256, cus=256)[0] == 0               # no width fits one round: the throughput kernel
+    assert pkg.small_plan_3x3_full(10, 128, 128, cus=256)[:4] == (1, 2, 2, 2)
+    assert pkg.small_plan_3x3_full(41, 128, 128, cus=256)[:4] == (1, 2, 1, 4) and pkg.small_plan_3x3(42, 128, 128, cus=256)[0] == 0
     assert pkg.small_plan_3x3(1, 24, 64, cus=256)[0] == 0                  # C % 16: throughput kernel only
     assert pkg.small_plan_3x3(1, 256, 256, cus=256, H=28, W=28)[0] == 0    # 14x14 only
     # every wave of the S workgroups gets a task: 4 S <= (C / 16) * (4 / PR)
     for C in (16, 32, 48, 64, 96, 128, 192, 256, 384, 512):
         for N in (1, 2, 3, 5):
-            use, pr, sp, wgs = pkg.small_plan_3x3(N, C, 64, cus=256)
+            use, pr, sp, ct, wgs = pkg.small_plan_3x3_full(N, C, 64, cus=256)
+            assert ct in (1, 2, 4) and (ct == 1 or pr == 2)
             if use and sp > 1:
                 assert 4 * sp <= (C // 16) * (4 // pr) and 1 <= sp <= 8 and pr in (1, 2, 4), (C, N, pr, sp)
                 assert wgs <= 256

@@ -48,6 +48,7 @@ def test_conv3x3_latency_forms_agree(N, C, K, pkg, O, torch_dev, knobs):
     want = O.conv3x3_bn_relu_direct(x, w, s, b)
     scale = float(np.abs(want).max())
     knobs.set("WINO_3X3_ALGO", "small")
+    knobs.set("WINO_SMALL_CT", 1)
     nsuper = C // 16
     forms = [(pr, sp) for pr in (4, 2, 1) for sp in (1, 2, 3, 4, 5, 8) if 4 * sp <= nsuper * (4 // pr) or sp == 1]
     assert forms
@@ -71,7 +72,50 @@ def test_conv3x3_latency_forms_agree(N, C, K, pkg, O, torch_dev, knobs):
         assert float((out - ref).abs().max()) < 4e-6 * scale, (pr, sp)
     knobs.unset("WINO_SMALL_PR")
     knobs.unset("WINO_SMALL_SPLIT")
+    knobs.unset("WINO_SMALL_CT")
     knobs.unset("WINO_3X3_ALGO")
+    auto = pkg.conv3x3_bn_relu(xt, U, bt, st)
+    assert float((auto - ref).abs().max()) < 4e-6 * scale
+    assert pkg.tickets_in_use() == 0
+
+
+@pytest.mark.parametrize("N,C,K", [(1, 256, 256), (4, 256, 256), (7, 128, 128), (3, 64, 192), (5, 32, 64), (2, 48, 128),
+                                   (9, 512, 64)])
+def test_conv3x3_latency_wide_blocks_agree(N, C, K, pkg, O, torch_dev, knobs):
+    """The wider blocks of the latency kernel (CT MFMA tiles per wave side by side, two point rows per task,
+    operands prefetched progressively; wino_f2_small2_kernel): every (CT, S) gives the fp64 oracle's values on
+    NaN-filled outputs (ragged last tile block and ring included), bitwise reproducibly, counters at zero."""
+    torch, dev = torch_dev
+    (x, w, s, b), (xt, wt, st, bt) = _layer(torch_dev, 300 + N + C, N, C, K)
+    U = pkg.filter_transform_f2(wt)
+    want = O.conv3x3_bn_relu_direct(x, w, s, b)
+    scale = float(np.abs(want).max())
+    knobs.set("WINO_3X3_ALGO", "small")
+    nsuper = C // 16
+    ref = None
+    for ct in (2, 4):
+        knobs.set("WINO_SMALL_CT", ct)
+        for sp in (1, 2, 3, 4, 8):
+            if sp > 1 and 4 * sp > nsuper * 2:
+                continue
+            knobs.set("WINO_SMALL_SPLIT", sp)
+            use, gpr, gsp, gct, wgs = pkg.small_plan_3x3_full(N, C, K)
+            assert (use, gpr, gsp, gct) == (1, 2, sp, ct), (ct, sp)
+            assert wgs == -(-N * 49 // 16) * (K // (16 * ct)) * sp
+            out = torch.full((N, 16, 16, K), float("nan"), device=dev)
+            pkg.conv3x3_bn_relu(xt, U, bt, st, out=out)
+            assert pkg.tickets_in_use() == 0, (ct, sp)
+            got = out.cpu().numpy()
+            assert not np.isnan(got).any(), (ct, sp)
+            assert O.rel_error(got, want) < TIGHT, (ct, sp, O.rel_error(got, want))
+            assert (got[:, _ring(), :] == 0).all(), (ct, sp)
+            for _ in range(3):
+                assert torch.equal(pkg.conv3x3_bn_relu(xt, U, bt, st), out), (ct, sp)
+            if ref is None:
+                ref = out
+            assert float((out - ref).abs().max()) < 4e-6 * scale, (ct, sp)
+    for k in ("WINO_SMALL_CT", "WINO_SMALL_SPLIT", "WINO_3X3_ALGO"):
+        knobs.unset(k)
     auto = pkg.conv3x3_bn_relu(xt, U, bt, st)
     assert float((auto - ref).abs().max()) < 4e-6 * scale
     assert pkg.tickets_in_use() == 0
@@ -170,7 +214,7 @@ def test_one_by_one_latency_forms_agree(M, Cin, Kout, relu, pkg, torch_dev, knob
 
 
 # ------------------------------------------------------------------ recovery after an aborted launch
-@pytest.mark.parametrize("kind", ["3x3 throughput", "3x3 latency", "1x1"])
+@pytest.mark.parametrize("kind", ["3x3 throughput", "3x3 latency", "3x3 latency wide", "1x1"])
 def test_a_dirty_ticket_counter_is_reported_and_reset_recovers(kind, pkg, torch_dev, knobs):
     """The reference holds no state between calls and exits on the first CUDA error (Kernel128_winograd.cu:16-22,
     236-256).  The one piece of state this library keeps is the ticket counters of a stream's scratch, zero
@@ -189,14 +233,16 @@ def test_a_dirty_ticket_counter_is_reported_and_reset_recovers(kind, pkg, torch_
             run = lambda: pkg.conv1x1_bn(A, Bm, b, s, True)
             n_tickets = 8
         else:
-            N = 40 if kind == "3x3 throughput" else 1
+            N = {"3x3 throughput": 40, "3x3 latency": 1, "3x3 latency wide": 4}[kind]
             if kind == "3x3 throughput":
                 knobs.set("WINO_3X3_ALGO", "big")
                 knobs.set("WINO_SK_GRID", "256")
             x, w, s, b = mk(N, 16, 16, 256), mk(256, 256, 3, 3), mk(256), mk(256)
             U = pkg.filter_transform_f2(w)
             run = lambda: pkg.conv3x3_bn_relu(x, U, b, s)
-            n_tickets = 64 if kind == "3x3 latency" else 8 * 4 * ((N * 49 + 63) // 64)
+            if kind == "3x3 latency wide":
+                assert pkg.small_plan_3x3_full(N, 256, 256) == (1, 2, 2, 2, 208)
+            n_tickets = {"3x3 latency": 64, "3x3 latency wide": 104}.get(kind, 8 * 4 * ((N * 49 + 63) // 64))
         ref = run().clone()
         assert pkg.tickets_in_use() == 0
         pkg.stream_check()

@@ -19,7 +19,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "quick"
 
 
 def knob(**kw):
-    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SMALL_RT",
+    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_SMALL_CT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SMALL_RT",
               "WINO_1X1_SMALL_CT"):
         os.environ.pop(k, None)
     for k, v in kw.items():
@@ -46,8 +46,8 @@ def conv3(C, N, **kw):
     torch.cuda.synchronize()
     knob(**kw)
     tag = " ".join("%s=%s" % (k.replace("WINO_", "").lower(), v) for k, v in kw.items()) or "auto"
-    use, pr, sp, wgs = pkg.small_plan_3x3(N, C, C)
-    form = "small pr%d s%d" % (pr, sp) if use else "big"
+    use, pr, sp, ct, wgs = pkg.small_plan_3x3_full(N, C, C)
+    form = "small 1x%d pr%d s%d %d wgs" % (ct, pr, sp, wgs) if use else "big"
     run("3x3 C=%d N=%d [%s -> %s]" % (C, N, tag, form), lambda: pkg.conv3x3_bn_relu(x, U, b, s, out=out))
     knob()
 
@@ -79,6 +79,26 @@ if mode == "explore1":   # the 1x1 latency form: every block shape and K-split a
                     if N >= 12 and (rt, ct) == (1, 1):
                         continue
                     conv1(Cin, Kout, N, WINO_1X1_ALGO="small", WINO_1X1_SMALL_KS=ks, WINO_1X1_SMALL_RT=rt, WINO_1X1_SMALL_CT=ct)
+    for c in cases:
+        print(json.dumps(c), flush=True)
+    sys.exit(0)
+if mode == "explore3":   # the 3x3 latency kernel's block widths between one image and the throughput kernel's range
+    for C, Ns in ((256, (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 21, 24)), (128, (1, 2, 4, 6, 8, 10, 12, 16, 20, 24, 32, 41, 42)),
+                  (64, (1, 4, 16, 41, 83, 84)), (192, (1, 3, 6, 10, 14, 20, 27, 28)), (384, (1, 2, 4, 6, 10, 13, 14)),
+                  (512, (1, 2, 3, 5, 8, 10, 11))):
+        nsuper = C // 16
+        for N in Ns:
+            conv3(C, N)
+            conv3(C, N, WINO_3X3_ALGO="big")
+            if C not in (128, 256) and N not in (Ns[0], Ns[len(Ns) // 2]):
+                continue
+            for ct in (1, 2, 4):
+                if C % (16 * ct):
+                    continue
+                blocks = -(-N * 49 // 16) * (C // (16 * ct))
+                if blocks > 300:
+                    continue
+                conv3(C, N, WINO_3X3_ALGO="small", WINO_SMALL_CT=ct)
     for c in cases:
         print(json.dumps(c), flush=True)
     sys.exit(0)
