@@ -120,16 +120,16 @@ if mode == "explore":   # beyond one round of blocks / workgroups: where do the 
         print(json.dumps(c), flush=True)
     sys.exit(0)
 for C in (256, 128):
-    for N in (1, 2, 3, 4, 5, 6, 8, 16) if mode == "full" else (1, 2, 4, 16):
+    for N in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32) if mode == "full" else (1, 2, 4, 16):
         conv3(C, N)
         conv3(C, N, WINO_3X3_ALGO="big")
     forms = [(4, 1), (4, 2), (4, 4), (2, 2), (2, 4), (2, 8), (1, 4), (1, 8)]
     for N in (1, 2, 3, 4) if mode == "full" else (1, 2):
         for pr, sp in forms:
             if 4 * sp <= (C // 16) * (4 // pr) and ((N * 49 + 15) // 16) * (C // 16) * sp <= 512:
-                conv3(C, N, **small(pr, sp))
+                conv3(C, N, WINO_SMALL_CT=1, **small(pr, sp))
 for Cin, Kout in ((1024, 256), (512, 128), (128, 512), (256, 1024)):
-    for N in (1, 2, 3, 4, 6, 8) if mode == "full" else (1, 2, 4):
+    for N in (1, 2, 3, 4, 6, 8, 12, 16) if mode == "full" else (1, 2, 4):
         conv1(Cin, Kout, N)
         conv1(Cin, Kout, N, WINO_1X1_ALGO="big")
         conv1(Cin, Kout, N, WINO_1X1_ALGO="small")
