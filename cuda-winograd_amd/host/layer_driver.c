@@ -41,16 +41,28 @@
 
 /* ---------------------------------------------------------------- configuration */
 static int g_batch = 0, g_gpus = 0, g_quiet = -1, g_alias = -1, g_compat = -1;
-static wino_driver_result g_last;
+/* The last call's result and tensors are per calling thread: the six argument-less entry points and the
+ * wino_driver_last_* accessors may be used from several host threads at once, each seeing its own last call (the
+ * reference is single-threaded, Test.c:13-56; the settings above stay process-wide). */
+static __thread wino_driver_result g_last;
 
 /* what the last kernel_*() call ran, kept for wino_driver_cpu_baseline() */
-static struct {
+static __thread struct {
   int kind, N, C, K, relu;
   float *in, *w, *bias, *scale, *out;
 } g_kept;
 static void drop_kept(void) {
   free(g_kept.in); free(g_kept.w); free(g_kept.bias); free(g_kept.scale); free(g_kept.out);
   memset(&g_kept, 0, sizeof g_kept);
+}
+/* a thread that called an entry point frees what it kept when it exits */
+static pthread_key_t g_kept_key;
+static pthread_once_t g_kept_once = PTHREAD_ONCE_INIT;
+static void kept_at_thread_exit(void* unused) { (void)unused; drop_kept(); }
+static void kept_key_init(void) { pthread_key_create(&g_kept_key, kept_at_thread_exit); }
+static void kept_arm(void) {
+  pthread_once(&g_kept_once, kept_key_init);
+  pthread_setspecific(g_kept_key, (void*)&g_kept);   /* any non-NULL value: the destructor then runs */
 }
 
 static int env_int(const char* name, int dflt) {
@@ -376,6 +388,7 @@ static int run_layer(const layer_t* ly) {
 
   /* keep what wino_driver_cpu_baseline() needs: inputs, direct-form weights, BN, the GPU output */
   drop_kept();
+  kept_arm();
   g_kept.kind = kind; g_kept.N = N; g_kept.C = C; g_kept.K = K; g_kept.relu = relu;
   g_kept.in = h_in; g_kept.w = h_w_cmp; g_kept.bias = h_bias; g_kept.scale = h_scale; g_kept.out = h_out;
   if (h_w_wino != h_w_cmp) free(h_w_wino);

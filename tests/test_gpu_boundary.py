@@ -105,6 +105,49 @@ def test_entry_point_outputs_match_the_oracle(mode, data_dir, pkg, O, golden_out
     assert O.rel_error(got.reshape(want.shape), want) < TIGHT
 
 
+def test_entry_points_from_two_host_threads(data_dir, pkg, O, golden_outputs):
+    """The driver keeps the last call's result and tensors per calling thread (the reference is single-threaded,
+    Test.c:13-56): two host threads call different entry points at the same time, each reads back ITS call's
+    output, and both match the golden vectors."""
+    import threading
+    L = pkg.lib()
+    cwd = os.getcwd()
+    os.chdir(data_dir)
+    got, errs = {}, []
+
+    def work(mode):
+        try:
+            for _ in range(3):
+                getattr(L, LAYERS[mode])()
+                n = ctypes.c_size_t()
+                p = L.wino_driver_last_output(ctypes.byref(n))
+                got[mode] = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+                res = pkg.DriverResult()
+                assert L.wino_driver_last_result(ctypes.byref(res)) == 0
+                assert res.N == 1 and res.max_rel_err < TIGHT
+        except Exception as e:   # noqa: BLE001 -- reported in the main thread
+            errs.append((mode, repr(e)))
+
+    try:
+        L.wino_driver_set_quiet(1)
+        L.wino_driver_set_batch(1)
+        L.wino_driver_set_gpus(1)
+        ts = [threading.Thread(target=work, args=(m,)) for m in (2, 5, 0)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        L.wino_driver_set_quiet(0)
+        os.chdir(cwd)
+    assert not errs, errs
+    for mode in (2, 5):
+        want = golden_outputs[LAYERS[mode]]
+        assert O.rel_error(got[mode].reshape(want.shape), want) < TIGHT, mode
+    g0 = got[0].reshape(1, 16, 16, 128)
+    assert O.rel_error(g0[:, 1:15, 1:15, :], golden_outputs[LAYERS[0]].reshape(1, 14, 14, 128)) < TIGHT
+
+
 @pytest.mark.parametrize("mode,N,G", [(1, 8, 2), (1, 9, 4), (4, 6, 2), (0, 128, 2), (1, 128, 8)])
 def test_multi_gpu_driver_path_on_one_gpu(mode, N, G, data_dir, pkg, O):
     """layer_driver.c's batch split -- one host thread and one stream per job, common start barrier,
