@@ -33,6 +33,8 @@
 //      slab / ticket rules as the throughput kernel (wino_f2_fused_kernel.h).
 // Requires C % 16 == 0 and the 14x14 map (the dispatcher takes the throughput kernel otherwise).
 // Same arithmetic, same packed filter buffer and same output contract as the big kernel.
+// Two kernels: wino_f2_small_kernel<PR> (16 x 16 blocks, the N = 1 forms above) and, below it,
+// wino_f2_small2_kernel<CT> (blocks of 16 tiles x 32 / 64 out-channels per wave for a few images up to ~20).
 #pragma once
 #include "wino_f2_fused_kernel.h"
 
@@ -50,7 +52,7 @@ struct SmallParams {
   const float* bnScale;
   float* out;
   int N, C, K, relu;
-  float* slabs;              // [block][S] x 4 KB (S > 1 only)
+  float* slabs;              // [block][S] x (block width / 16) x 4 KB (S > 1 only)
   unsigned* tickets;         // [block]
   unsigned* err;             // host-visible word: set when a ticket counter was found dirty (S > 1 only)
   unsigned long long* dbg;   // timeline build only (DIAG, tools/small_timeline): 8 stamps per workgroup
