@@ -49,7 +49,6 @@ struct Knobs {
   int sk_kp;          // WINO_SK_KP: 1 (default) the 3x3 stream-K tail per k-block, ranges placed in phase order; 0 round 2's
                       // item-major list in launch order; 2 / 3 only the groups / only the phase order (A/B measurements)
   int small_split;    // WINO_SMALL_SPLIT: C-split S of the 3x3 latency kernel (0 = policy)
-  int small_pr;       // WINO_SMALL_PR: point rows per task of the 3x3 latency kernel, 1 / 2 / 4 (0 = policy)
   int small3_ct;      // WINO_SMALL_CT: MFMA tiles per wave (block width / 16) of the 3x3 latency kernel, 1 / 2 / 4 (0 = policy)
   int algo_1x1;       // WINO_1X1_ALGO: 0 automatic, 1 "big" (LDS-staged kernel), 2 "small" (latency kernel)
   int small_ks;       // WINO_1X1_SMALL_KS: K-split of the 1x1 latency kernel, 1 / 2 / 4 (0 = policy)

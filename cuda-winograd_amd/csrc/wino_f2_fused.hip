@@ -325,27 +325,29 @@ static int check_conv3x3(int N, int H, int W, int C, int K) {
 
 // Two kernels, same arithmetic: the throughput kernel (64-tile x 64-out-channel items, 8-wave
 // workgroups, whole-item rounds + stream-K tail) and the one-wave-per-SIMD latency kernel (blocks of 16 tiles
-// x 16 CT out-channels, CT = 1, 2 or 4; 14x14 maps only), which wins while its blocks fit ONE round of the CUs
-// (measured at 64 ... 512 channels, N = 1..41: e.g. 256 channels N = 8: 23 us against 32, N = 16: 32 against 36;
-// 128 channels N = 16: 15 against 24; a second round of blocks doubles the latency kernel's time at once).
+// x 16 CT out-channels, CT = 1, 2 or 4; 14x14 maps only; wino_f2_small_kernel.h), which wins while its blocks fit
+// ONE round of the CUs (a second round of blocks doubles the latency kernel's time at once).
 // While the blocks leave CUs idle the latency kernel also splits a block's contraction over S workgroups
-// (C-split; wino_f2_small_kernel.h): S as large as the idle CUs allow (at most 8), then the coarsest task
-// (PR point rows of a 16-channel super-chunk) that still gives every wave of the S workgroups one.
-// Among the block widths that fit, the one with the shortest modelled time:
-//   T = 6.07 us + tasks per wave x (0.0829 us x pixel loads + (0.0523 + 0.0226 fill) us x filter loads) + split cost,
-// fill = workgroups / CUs, split cost 0.1 / 1.3 / 4.8 us at CT = 1 / 2 / 4 when S > 1, the 16 x 16 kernel's loads 14 %
-// dearer (least squares over 172 measured forms, rms 0.6 us: tools/latency_cases.py explore3, profiles/r3/; the
-// per-load prices are a CU's vector memory path shared by its 4 waves -- a pixel fragment touches twice the cache
-// lines of a filter fragment -- and the split cost is the slab round trip, whose bytes grow with the block).
-// WINO_3X3_ALGO=big|small, WINO_SMALL_SPLIT, WINO_SMALL_PR, WINO_SMALL_CT override.
+// (C-split): S as large as the idle CUs allow (at most 8, and every wave of the S workgroups gets a task in the
+// first round: 4 S <= 2 C / 16).
+// Among the block widths that fit, the one with the shortest modelled time (small_form below; least squares over the
+// forms measured by tools/latency_cases.py explore3, profiles/r3/), and only while that beats the throughput kernel's
+// fitted time in this regime, 18.8 us + 0.0174 us x C + 1.94 us x (chunk iterations per CU) (54 points at 64 ... 512
+// channels, within 3 us): the latency kernel's price per task grows with C, and from 384 channels on a full round of
+// its blocks is the slower launch.
+// WINO_3X3_ALGO=big|small, WINO_SMALL_SPLIT, WINO_SMALL_CT override.
 struct SmallPlan {
   bool use;
-  int pr, split, nT16;   // nT16: blocks of 16 tiles
+  int split, nT16;       // nT16: blocks of 16 tiles
   size_t blocks;
-  int ct;                // MFMA tiles per wave, side by side (1: wino_f2_small_kernel; 2, 4: wino_f2_small2_kernel, pr = 2)
+  int ct;                // MFMA tiles per wave, side by side
   double t_us;           // the model's time
 };
-// The block width ct on `cus` CUs: its blocks, the C-split and the task grain.  false if its blocks do not fit one round.
+// T = 5.70 us + rounds x (0.487 + (0.509 + 0.229 fill) CT) us + split cost: a round is 8 whole-line pixel loads per wave
+// (the workgroup's 32, shared through LDS) and 8 CT filter-fragment loads; fill = workgroups / CUs; the split cost (slab
+// round trip, growing with the block) 0.4 / 1.2 / 4.5 us at CT = 1 / 2 / 4.  148 measured forms, rms 0.85 us.
+constexpr double SMALL_T0 = 5.70, SMALL_ROUND = 0.487, SMALL_FLT = 0.509, SMALL_FLT_FILL = 0.2285;
+// The block width ct on `cus` CUs: its blocks and the C-split.  false if its blocks do not fit one round.
 static bool small_form(int N, int C, int K, int cus, int ct, SmallPlan* pl) {
   if ((K % (16 * ct)) != 0) return false;
   pl->ct = ct;
@@ -353,28 +355,21 @@ static bool small_form(int N, int C, int K, int cus, int ct, SmallPlan* pl) {
   const long long blocks = (long long)pl->nT16 * (K / (16 * ct));
   pl->blocks = (size_t)blocks;
   pl->split = 1;
-  pl->pr = ct > 1 ? 2 : 4;
   pl->t_us = 0;
   if (blocks > cus) return false;
-  const int nsuper = C / 16;
-  int smax = (int)(cus / blocks);
-  if (smax > SMALL_MAX_SPLIT) smax = SMALL_MAX_SPLIT;
-  if (smax < 1) smax = 1;
-  bool found = false;
-  for (int sp = smax; sp >= 1 && !found; sp--)
-    for (int pr = (ct > 1 ? 2 : 4); pr >= (ct > 1 ? 2 : 1) && !found; pr >>= 1)
-      if (SMALL_WAVES * sp <= nsuper * (4 / pr)) { pl->split = sp; pl->pr = pr; found = true; }
-  const int ntask = nsuper * (4 / pl->pr), waves = SMALL_WAVES * pl->split;
-  const int px_loads = pl->pr == 4 ? 16 : pl->pr == 2 ? 12 : 8, flt_loads = 4 * pl->pr * ct;
-  const double fill = (double)(blocks * pl->split) / cus;
-  const double split_us = pl->split > 1 ? (ct == 1 ? 0.1 : ct == 2 ? 1.34 : 4.76) : 0.0;
-  pl->t_us = 6.07 + (double)((ntask + waves - 1) / waves) *
-                        (0.0829 * px_loads + (0.0523 + 0.0226 * fill) * flt_loads + (ct == 1 ? 0.0117 * (px_loads + flt_loads) : 0.0)) +
-             split_us;
+  const int ntask = (C / 16) * 2;
+  int sp = (int)(cus / blocks);
+  if (sp > SMALL_MAX_SPLIT) sp = SMALL_MAX_SPLIT;
+  while (sp > 1 && SMALL_WAVES * sp > ntask) sp--;
+  pl->split = sp;
+  const int waves = SMALL_WAVES * sp;
+  const double fill = (double)(blocks * sp) / cus;
+  const double split_us = sp > 1 ? (ct == 1 ? 0.38 : ct == 2 ? 1.21 : 4.45) : 0.0;
+  pl->t_us = SMALL_T0 + (double)((ntask + waves - 1) / waves) * (SMALL_ROUND + (SMALL_FLT + SMALL_FLT_FILL * fill) * ct) + split_us;
   return true;
 }
 static SmallPlan small_plan(int N, int H, int W, int C, int K, int cus) {
-  SmallPlan pl = {false, 4, 1, 0, 0, 1, 0.0};
+  SmallPlan pl = {false, 1, 0, 0, 1, 0.0};
   if (H != WINO_PQ || W != WINO_PQ || (C % 16) != 0) return pl;
   const Knobs kn = knobs();
   if (kn.small3_ct == 1 || kn.small3_ct == 2 || kn.small3_ct == 4) {
@@ -385,10 +380,6 @@ static SmallPlan small_plan(int N, int H, int W, int C, int K, int cus) {
       SmallPlan f = pl;
       if (small_form(N, C, K, cus, ct, &f) && (!best.use || f.t_us < best.t_us)) { best = f; best.use = true; }
     }
-    // ... and only while that beats the throughput kernel, whose time in this regime is 18.8 us + 0.0174 us x C +
-    // 1.94 us x (chunk iterations per CU) (same sweep, 54 points at 64 ... 512 channels, within 3 us): the latency
-    // kernel's price per task grows with C, and from 384 channels on a full round of its blocks is the slower launch
-    // (384 channels N = 10: 47.7 us against 41.7; 512 channels N = 8: 61 against 52)
     const double items = (double)((N * WINO_TILES + TB - 1) / TB) * (K / KB);
     const double t_big = 18.8 + 0.0174 * C + 1.94 * items * (C / BC) / cus;
     if (best.use && 1.08 * best.t_us < t_big) pl = best;   // (the margin: the model is 2-3 us short on a full round of wide blocks)
@@ -398,7 +389,6 @@ static SmallPlan small_plan(int N, int H, int W, int C, int K, int cus) {
   if (kn.algo_3x3 == 2) pl.use = pl.nT16 <= 65535 && (K % (16 * pl.ct)) == 0;
   if (!pl.use) return pl;
   if (kn.small_split >= 1 && kn.small_split <= SMALL_MAX_SPLIT) pl.split = kn.small_split;
-  if (pl.ct == 1 && (kn.small_pr == 1 || kn.small_pr == 2 || kn.small_pr == 4)) pl.pr = kn.small_pr;
   return pl;
 }
 static int small_scratch(int dev, hipStream_t s, const SmallPlan& pl, SkBufs* bufs) {
@@ -478,10 +468,8 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
     if (int rc = small_scratch(dev, s, sp, &bufs)) return rc;
     const SmallParams prm = {in, U, bnBias, bnScale, out, N, C, K, relu, bufs.slabs, bufs.tickets, bufs.err, nullptr};
     const dim3 grid(K / (16 * sp.ct), sp.nT16, sp.split), block(64 * SMALL_WAVES);   // x = out-channel block: see the kernel
-    if (sp.ct == 4) hipLaunchKernelGGL(wino_f2_small2_kernel<4>, grid, block, 0, s, prm);
-    else if (sp.ct == 2) hipLaunchKernelGGL(wino_f2_small2_kernel<2>, grid, block, 0, s, prm);
-    else if (sp.pr == 4) hipLaunchKernelGGL(wino_f2_small_kernel<4>, grid, block, 0, s, prm);
-    else if (sp.pr == 2) hipLaunchKernelGGL(wino_f2_small_kernel<2>, grid, block, 0, s, prm);
+    if (sp.ct == 4) hipLaunchKernelGGL(wino_f2_small_kernel<4>, grid, block, 0, s, prm);
+    else if (sp.ct == 2) hipLaunchKernelGGL(wino_f2_small_kernel<2>, grid, block, 0, s, prm);
     else hipLaunchKernelGGL(wino_f2_small_kernel<1>, grid, block, 0, s, prm);
     const int rc = launch_status("wino_f2_small_kernel");
     if (rc && sp.split > 1) sk_mark_failed(dev, s);
@@ -572,7 +560,7 @@ int wino_conv3x3_small_plan(int N, int H, int W, int C, int K, int cus, int* use
   if (int rc = check_conv3x3(N, H, W, C, K)) return rc;
   const SmallPlan pl = small_plan(N, H, W, C, K, cus);
   *use = pl.use;
-  *point_rows = pl.pr;
+  *point_rows = 2;
   *split = pl.split;
   *workgroups = pl.use ? (int)(pl.blocks * pl.split) : 0;
   return WINO_OK;

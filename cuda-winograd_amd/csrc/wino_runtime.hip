@@ -145,7 +145,6 @@ void read_knobs() {
   k.sk_1x1_grid = env_num("WINO_1X1_SK_GRID", 0);
   k.sk_kp = env_num("WINO_SK_KP", 1);
   k.small_split = env_num("WINO_SMALL_SPLIT", 0);
-  k.small_pr = env_num("WINO_SMALL_PR", 0);
   k.small3_ct = env_num("WINO_SMALL_CT", 0);
   const char* algo1 = getenv("WINO_1X1_ALGO");
   k.algo_1x1 = algo1 && !strcmp(algo1, "big") ? 1 : algo1 && !strcmp(algo1, "small") ? 2 : 0;

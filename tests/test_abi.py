@@ -300,32 +300,33 @@ def test_one_by_one_plan_covers_every_step_once(M, Cin, Kout, cus, grid_env, pkg
 
 def test_latency_plans_at_the_reference_point(pkg, knobs):
     """The reference's own protocol is ONE image (`./Test 0..5`).  On 256 CUs the policy must put those layers
-    on (nearly) every CU: the 3x3 layers as 64 blocks x 4 C-splits (256 channels) / 32 blocks x 8 with one
-    point row per task (128 channels), the 1x1 layers as 16 x 16 blocks with the K-split that fills the CUs;
+    on (nearly) every CU: the 3x3 layers as 64 blocks x 4 C-splits (256 channels) / 32 blocks x 4 (128 channels), the 1x1 layers as 16 x 16 blocks with the K-split that fills the CUs;
     and hand over to the throughput / tiled kernels where the measurements (profiles/r3) say so."""
-    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_SMALL_CT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SK",
+    for k in ("WINO_3X3_ALGO", "WINO_SMALL_SPLIT", "WINO_SMALL_CT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SK",
               "WINO_1X1_SK_GRID"):
         knobs.unset(k)
-    assert pkg.small_plan_3x3(1, 256, 256, cus=256) == (1, 4, 4, 256)
-    assert pkg.small_plan_3x3(1, 128, 128, cus=256) == (1, 1, 8, 256)
-    # beyond one image: (use, point rows, C-split, block width / 16, workgroups) -- wider blocks as the batch grows
+    # (use, point rows per task, C-split, block width / 16, workgroups)
+    assert pkg.small_plan_3x3_full(1, 256, 256, cus=256) == (1, 2, 4, 1, 256)
+    assert pkg.small_plan_3x3_full(1, 128, 128, cus=256) == (1, 2, 4, 1, 128)     # 4 S <= 2 C / 16: every wave has a task
+    # beyond one image: wider blocks as the batch grows
     assert pkg.small_plan_3x3_full(2, 256, 256, cus=256) == (1, 2, 4, 2, 224)
     assert pkg.small_plan_3x3_full(5, 256, 256, cus=256) == (1, 2, 2, 2, 256)
     assert pkg.small_plan_3x3_full(8, 256, 256, cus=256) == (1, 2, 1, 2, 200)
     assert pkg.small_plan_3x3_full(16, 256, 256, cus=256) == (1, 2, 1, 4, 196)
     assert pkg.small_plan_3x3_full(20, 256, 256, cus=256)[:4] == (1, 2, 1, 4)
     assert pkg.small_plan_3x3(21, 256, 256, cus=256)[0] == 0               # no width fits one round: the throughput kernel
-    assert pkg.small_plan_3x3_full(10, 128, 128, cus=256)[:4] == (1, 2, 2, 2)
+    assert pkg.small_plan_3x3_full(10, 128, 128, cus=256)[:4] == (1, 2, 1, 1)
     assert pkg.small_plan_3x3_full(41, 128, 128, cus=256)[:4] == (1, 2, 1, 4) and pkg.small_plan_3x3(42, 128, 128, cus=256)[0] == 0
+    assert pkg.small_plan_3x3(10, 384, 384, cus=256)[0] == 0               # a full round of wide blocks at 384 channels loses
     assert pkg.small_plan_3x3(1, 24, 64, cus=256)[0] == 0                  # C % 16: throughput kernel only
     assert pkg.small_plan_3x3(1, 256, 256, cus=256, H=28, W=28)[0] == 0    # 14x14 only
     # every wave of the S workgroups gets a task: 4 S <= (C / 16) * (4 / PR)
     for C in (16, 32, 48, 64, 96, 128, 192, 256, 384, 512):
         for N in (1, 2, 3, 5):
             use, pr, sp, ct, wgs = pkg.small_plan_3x3_full(N, C, 64, cus=256)
-            assert ct in (1, 2, 4) and (ct == 1 or pr == 2)
+            assert ct in (1, 2, 4) and pr == 2
             if use and sp > 1:
-                assert 4 * sp <= (C // 16) * (4 // pr) and 1 <= sp <= 8 and pr in (1, 2, 4), (C, N, pr, sp)
+                assert 4 * sp <= (C // 16) * 2 and 1 <= sp <= 8, (C, N, sp)
                 assert wgs <= 256
     # (use, K-split, row tiles, column tiles, workgroups) at M = 196
     want = {(1024, 256): (1, 4, 1, 1, 208), (512, 128): (1, 4, 1, 1, 104), (128, 512): (1, 2, 1, 1, 208),

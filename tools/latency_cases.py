@@ -19,7 +19,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "quick"
 
 
 def knob(**kw):
-    for k in ("WINO_3X3_ALGO", "WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_SMALL_CT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SMALL_RT",
+    for k in ("WINO_3X3_ALGO", "WINO_SMALL_SPLIT", "WINO_SMALL_CT", "WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SMALL_RT",
               "WINO_1X1_SMALL_CT"):
         os.environ.pop(k, None)
     for k, v in kw.items():
@@ -66,7 +66,7 @@ def conv1(Cin, Kout, N, **kw):
     knob()
 
 
-small = lambda pr, sp: dict(WINO_3X3_ALGO="small", WINO_SMALL_PR=pr, WINO_SMALL_SPLIT=sp)
+small = lambda ct, sp: dict(WINO_3X3_ALGO="small", WINO_SMALL_CT=ct, WINO_SMALL_SPLIT=sp)
 if mode == "explore1":   # the 1x1 latency form: every block shape and K-split against the tiled kernel
     for Cin, Kout in ((1024, 256), (512, 128), (128, 512), (256, 1024)):
         for N in (1, 2, 3, 4, 6, 8, 12, 16, 24):
@@ -82,15 +82,15 @@ if mode == "explore1":   # the 1x1 latency form: every block shape and K-split a
     for c in cases:
         print(json.dumps(c), flush=True)
     sys.exit(0)
-if mode == "explore3":   # the 3x3 latency kernel's block widths between one image and the throughput kernel's range
-    for C, Ns in ((256, (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 21, 24)), (128, (1, 2, 4, 6, 8, 10, 12, 16, 20, 24, 32, 41, 42)),
-                  (64, (1, 4, 16, 41, 83, 84)), (192, (1, 3, 6, 10, 14, 20, 27, 28)), (384, (1, 2, 4, 6, 10, 13, 14)),
+if mode == "explore3":   # the 3x3 latency kernel's block widths and splits, one image up to the throughput kernel's range
+    for C, Ns in ((256, (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 21, 24)), (128, (1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32, 41, 42)),
+                  (64, (1, 2, 4, 16, 41, 83, 84)), (192, (1, 3, 6, 10, 14, 20, 27, 28)), (384, (1, 2, 4, 6, 10, 13, 14)),
                   (512, (1, 2, 3, 5, 8, 10, 11))):
         nsuper = C // 16
         for N in Ns:
             conv3(C, N)
             conv3(C, N, WINO_3X3_ALGO="big")
-            if C not in (128, 256) and N not in (Ns[0], Ns[len(Ns) // 2]):
+            if C not in (128, 256) and N not in (Ns[0], Ns[1], Ns[len(Ns) // 2]):
                 continue
             for ct in (1, 2, 4):
                 if C % (16 * ct):
@@ -98,19 +98,21 @@ if mode == "explore3":   # the 3x3 latency kernel's block widths between one ima
                 blocks = -(-N * 49 // 16) * (C // (16 * ct))
                 if blocks > 300:
                     continue
-                conv3(C, N, WINO_3X3_ALGO="small", WINO_SMALL_CT=ct)
+                smax = max(1, min(256 // blocks, nsuper // 2, 8))
+                for sp in sorted({smax, max(1, smax // 2)}):
+                    conv3(C, N, WINO_3X3_ALGO="small", WINO_SMALL_CT=ct, WINO_SMALL_SPLIT=sp)
     for c in cases:
         print(json.dumps(c), flush=True)
     sys.exit(0)
 if mode == "explore":   # beyond one round of blocks / workgroups: where do the latency forms stop paying?
     for N in (6, 8, 10, 12, 16, 20, 24):
         conv3(128, N, WINO_3X3_ALGO="big")
-        for pr, sp in ((4, 1), (2, 1), (1, 1), (2, 2), (1, 2)):
-            conv3(128, N, **small(pr, sp))
+        for ct, sp in ((1, 1), (2, 1), (4, 1), (1, 2), (2, 2)):
+            conv3(128, N, **small(ct, sp))
     for N in (3, 4, 5, 6, 8):
         conv3(256, N, WINO_3X3_ALGO="big")
-        for pr, sp in ((4, 1), (2, 1), (1, 1), (2, 2), (1, 2), (1, 4)):
-            conv3(256, N, **small(pr, sp))
+        for ct, sp in ((1, 1), (2, 1), (4, 1), (2, 2), (4, 2), (4, 4)):
+            conv3(256, N, **small(ct, sp))
     for Cin, Kout in ((1024, 256), (512, 128), (128, 512), (256, 1024)):
         for N in (1, 2, 3, 4, 6, 8, 12, 16):
             conv1(Cin, Kout, N, WINO_1X1_ALGO="big")
@@ -123,11 +125,11 @@ for C in (256, 128):
     for N in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32) if mode == "full" else (1, 2, 4, 16):
         conv3(C, N)
         conv3(C, N, WINO_3X3_ALGO="big")
-    forms = [(4, 1), (4, 2), (4, 4), (2, 2), (2, 4), (2, 8), (1, 4), (1, 8)]
+    forms = [(1, 1), (1, 2), (1, 4), (1, 8), (2, 2), (2, 4), (2, 8), (4, 4), (4, 8)]
     for N in (1, 2, 3, 4) if mode == "full" else (1, 2):
-        for pr, sp in forms:
-            if 4 * sp <= (C // 16) * (4 // pr) and ((N * 49 + 15) // 16) * (C // 16) * sp <= 512:
-                conv3(C, N, WINO_SMALL_CT=1, **small(pr, sp))
+        for ct, sp in forms:
+            if 4 * sp <= (C // 16) * 2 and ((N * 49 + 15) // 16) * (C // (16 * ct)) * sp <= 512:
+                conv3(C, N, **small(ct, sp))
 for Cin, Kout in ((1024, 256), (512, 128), (128, 512), (256, 1024)):
     for N in (1, 2, 3, 4, 6, 8, 12, 16) if mode == "full" else (1, 2, 4):
         conv1(Cin, Kout, N)

@@ -1,9 +1,9 @@
 // Developer tool: where the 3x3 latency kernel's time goes at the reference's N = 1 (per-workgroup timeline).
-// Launches the DIAG build of wino_f2_small_kernel<PR> (same source) back to back and prints, over the workgroups of
+// Launches the DIAG build of wino_f2_small_kernel<CT> (same source) back to back and prints, over the workgroups of
 // the LAST launch, the median / 90th percentile of each phase, separately for the finishers (the workgroup that drew
 // its block's last ticket) and the others, plus the spread of the workgroups' entry times.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Icuda-winograd_amd/csrc tools/small_timeline.hip -o tools/small_timeline
-//   tools/small_timeline C N PR S
+//   tools/small_timeline C N CT S
 #include "wino_f2_small_kernel.h"
 #include <algorithm>
 #include <cstdio>
@@ -13,12 +13,12 @@ using namespace wino::fused;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 namespace wino { void set_error(const char*, ...) {} int hip_fail(hipError_t, const char*) { return -1; } }
 
-template <int PR>
+template <int CT>
 static void run(int C, int N, int S) {
-  const int K = C, nT16 = (N * 49 + 15) / 16, blocks = nT16 * (K / 16);
+  const int K = C, nT16 = (N * 49 + 15) / 16, blocks = nT16 * (K / (16 * CT));
   float *in, *U, *b, *s, *out, *slabs; unsigned *tickets, *err; unsigned long long* dbg;
   CK(hipMalloc(&in, (size_t)N * 256 * C * 4)); CK(hipMalloc(&U, (size_t)16 * C * K * 4)); CK(hipMalloc(&b, K * 4)); CK(hipMalloc(&s, K * 4));
-  CK(hipMalloc(&out, (size_t)N * 256 * K * 4)); CK(hipMalloc(&slabs, (size_t)blocks * 8 * 4096)); CK(hipMalloc(&tickets, blocks * 4));
+  CK(hipMalloc(&out, (size_t)N * 256 * K * 4)); CK(hipMalloc(&slabs, (size_t)blocks * 8 * 4096 * CT)); CK(hipMalloc(&tickets, blocks * 4));
   CK(hipMalloc(&err, 64)); CK(hipMalloc(&dbg, (size_t)blocks * S * 64));
   CK(hipMemset(tickets, 0, blocks * 4)); CK(hipMemset(err, 0, 64));
   std::vector<float> h((size_t)16 * C * K);
@@ -27,15 +27,15 @@ static void run(int C, int N, int S) {
   CK(hipMemcpy(in, h.data(), (size_t)N * 256 * C * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b, h.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + K, K * 4, hipMemcpyHostToDevice));
   const SmallParams prm = {in, U, b, s, out, N, C, K, 1, slabs, tickets, err, dbg};
-  for (int i = 0; i < 200; i++) hipLaunchKernelGGL((wino_f2_small_kernel<PR, true>), dim3(K / 16, nT16, S), dim3(256), 0, 0, prm);
+  for (int i = 0; i < 200; i++) hipLaunchKernelGGL((wino_f2_small_kernel<CT, true>), dim3(K / (16 * CT), nT16, S), dim3(256), 0, 0, prm);
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> st((size_t)blocks * S * 8);
   CK(hipMemcpy(st.data(), dbg, st.size() * 8, hipMemcpyDeviceToHost));
   unsigned long long t0 = ~0ull, t1 = 0;
   for (size_t w = 0; w < (size_t)blocks * S; w++) { t0 = std::min(t0, st[w * 8]); t1 = std::max(t1, st[w * 8 + 7]); }
-  const char* names[7] = {"entry -> operands requested", "-> MFMAs + A^T m A done", "-> LDS level done", "-> slab drained",
+  const char* names[7] = {"entry -> first stage in LDS", "-> MFMAs + A^T m A done", "-> LDS level done", "-> slab drained",
                           "-> ticket drawn", "-> gather landed", "-> BN, stores drained"};
-  printf("C = %d, N = %d, PR = %d, S = %d: %d workgroups; first entry -> last exit %.2f us\n", C, N, PR, S, blocks * S, (t1 - t0) / 100.0);
+  printf("C = %d, N = %d, CT = %d, S = %d: %d workgroups; first entry -> last exit %.2f us\n", C, N, CT, S, blocks * S, (t1 - t0) / 100.0);
   for (int fin = 1; fin >= 0; fin--) {
     std::vector<double> ph[7], entry, exit_;
     for (size_t w = 0; w < (size_t)blocks * S; w++) {
@@ -62,7 +62,7 @@ static void run(int C, int N, int S) {
 }
 
 int main(int argc, char** argv) {
-  const int C = argc > 1 ? atoi(argv[1]) : 256, N = argc > 2 ? atoi(argv[2]) : 1, PR = argc > 3 ? atoi(argv[3]) : 4, S = argc > 4 ? atoi(argv[4]) : 4;
-  if (PR == 4) run<4>(C, N, S); else if (PR == 2) run<2>(C, N, S); else run<1>(C, N, S);
+  const int C = argc > 1 ? atoi(argv[1]) : 256, N = argc > 2 ? atoi(argv[2]) : 1, CT = argc > 3 ? atoi(argv[3]) : 1, S = argc > 4 ? atoi(argv[4]) : 4;
+  if (CT == 4) run<4>(C, N, S); else if (CT == 2) run<2>(C, N, S); else run<1>(C, N, S);
   return 0;
 }

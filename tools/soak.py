@@ -31,13 +31,13 @@ for (N, Cin, Kout, grid) in [(128, 1024, 256, 0), (128, 1024, 256, 512), (100, 5
     cfg1.append([N, Cin, Kout, grid, A, Bm, b, s, None])
 # 3x3 latency kernel: blocks shared by S workgroups through slabs + one ticket per workgroup (round 3); forms forced
 cfgs_small = []
-for (N, C, K, pr, sp, ct) in [(1, 256, 256, 4, 4, 1), (1, 128, 128, 1, 8, 1), (2, 256, 256, 4, 2, 1), (1, 256, 256, 2, 8, 1), (3, 128, 128, 2, 3, 1),
-                              (2, 128, 128, 1, 4, 1), (1, 64, 192, 1, 4, 1), (4, 128, 128, 4, 2, 1), (4, 256, 256, 2, 2, 2), (6, 256, 256, 2, 3, 4),
-                              (2, 256, 256, 2, 4, 2), (3, 128, 128, 2, 4, 2), (1, 64, 192, 2, 2, 4)]:
+for (N, C, K, sp, ct) in [(1, 256, 256, 4, 1), (1, 128, 128, 4, 1), (2, 256, 256, 2, 1), (1, 256, 256, 8, 2), (3, 128, 128, 3, 1),
+                          (2, 128, 128, 4, 2), (1, 64, 192, 2, 1), (4, 128, 128, 2, 1), (4, 256, 256, 2, 2), (6, 256, 256, 3, 4),
+                          (2, 256, 256, 4, 2), (3, 128, 128, 4, 2), (1, 64, 192, 2, 4), (1, 512, 512, 8, 4)]:
     x = torch.rand(N, 16, 16, C, device=dev) - 0.5
     U = pkg.filter_transform_f2(torch.rand(K, C, 3, 3, device=dev) - 0.5)
     b, s = torch.rand(K, device=dev) - 0.5, torch.rand(K, device=dev) - 0.5
-    cfgs_small.append([N, C, K, (pr, sp, ct), x, U, b, s, None])
+    cfgs_small.append([N, C, K, (sp, ct), x, U, b, s, None])
 side = torch.cuda.Stream()
 xs = torch.rand(64, 16, 16, 128, device=dev); Us = pkg.filter_transform_f2(torch.rand(128, 128, 3, 3, device=dev)); vs = torch.rand(128, device=dev)
 use_side = os.environ.get("SOAK_SIDE", "1") != "0"
@@ -45,8 +45,8 @@ t0, launches, bad = time.time(), 0, 0
 stats = {}
 while time.time() - t0 < budget:
     for c in cfgs_small:
-        N, C, K, (pr, sp, ct), x, U, b, s, ref = c
-        os.environ.update(WINO_3X3_ALGO="small", WINO_SMALL_PR=str(pr), WINO_SMALL_SPLIT=str(sp), WINO_SMALL_CT=str(ct))
+        N, C, K, (sp, ct), x, U, b, s, ref = c
+        os.environ.update(WINO_3X3_ALGO="small", WINO_SMALL_SPLIT=str(sp), WINO_SMALL_CT=str(ct))
         os.environ.pop("WINO_SK_GRID", None)
         L.wino_debug_reload_knobs()
         if use_side:
@@ -59,11 +59,11 @@ while time.time() - t0 < budget:
         for o in outs:
             if not torch.equal(o, ref):
                 bad += 1
-                st = stats.setdefault(("small", N, C, K, pr, sp, ct), [0, 0.0, 0, 0])
+                st = stats.setdefault(("small", N, C, K, sp, ct), [0, 0.0, 0, 0])
                 d = (o - ref).abs()
                 st[0] += 1; st[1] = max(st[1], float(d.max())); st[2] = max(st[2], int((d > 0).sum())); st[3] = max(st[3], int(torch.isnan(o).sum()))
     os.environ["WINO_3X3_ALGO"] = "big"
-    for k in ("WINO_SMALL_PR", "WINO_SMALL_SPLIT", "WINO_SMALL_CT"): os.environ.pop(k, None)
+    for k in ("WINO_SMALL_SPLIT", "WINO_SMALL_CT"): os.environ.pop(k, None)
     for c in cfgs:
         N, C, K, grid, x, U, b, s, ref = c
         if grid: os.environ["WINO_SK_GRID"] = str(grid)

@@ -20,7 +20,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 src = f"gpurun_out/prof_{tag}"
 dst = f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
-HOT = ("wino_f2_fused_kernel", "wino_f2_small2_kernel", "wino_f2_small_kernel", "conv1x1_bn_kernel", "conv1x1_small_kernel",
+HOT = ("wino_f2_fused_kernel", "wino_f2_small_kernel", "conv1x1_bn_kernel", "conv1x1_small_kernel",
        "f4_input_transform_kernel", "f4_output_transform_kernel", "f4_ring_kernel")
 
 
@@ -32,7 +32,7 @@ def short(name):
                 if m:
                     a = [x.strip() for x in m.group(1).split(",")]
                     return "conv1x1_bn_kernel<%sw%s>" % (a[1] if len(a) > 1 else "?", ",streamK" if len(a) > 3 and a[3] in ("true", "1") else "")
-            if h in ("wino_f2_small_kernel", "wino_f2_small2_kernel"):   # keep the form: <PR> / <CT>
+            if h == "wino_f2_small_kernel":   # keep the form: <CT>
                 m = re.search(h + r"<\s*(\d+)", name)
                 return h + ("<%s>" % m.group(1) if m else "")
             if h == "conv1x1_small_kernel":   # <KS, RT, CT>

@@ -8,7 +8,7 @@ import os
 import statistics
 import sys
 
-HOT = ("wino_f2_fused_kernel", "wino_f2_small2_kernel", "wino_f2_small_kernel", "conv1x1_bn_kernel", "conv1x1_small_kernel")
+HOT = ("wino_f2_fused_kernel", "wino_f2_small_kernel", "conv1x1_bn_kernel", "conv1x1_small_kernel")
 trace_dir, cases_path = sys.argv[1], sys.argv[2]
 f = max(glob.glob(os.path.join(trace_dir, "**/*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 rows = []
