@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "wino_residual_block_prepare", "wino_residual_block_prepare_hw", "wino_diag_conv3x3_clock",
     "wino_debug_tickets_in_use", "wino_stream_check", "wino_stream_reset_scratch", "wino_debug_poison_ticket",
     "wino_diag_last_clock", "wino_conv3x3_small_plan", "wino_conv1x1_small_plan", "wino_conv3x3_plan_groups", "wino_conv1x1_small_plan2",
-    "wino_conv3x3_small_plan2",
+    "wino_conv3x3_small_plan2", "wino_debug_conv1x1_models",
     # reference entry points + helpers (Kernel*.h, util.h)
     "kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in",
     "kernel_256_1_out", "get_parameter", "transpose", "getTimeMicroseconds64", "output_checker",
@@ -130,6 +130,7 @@ def lib() -> ctypes.CDLL:
     L.wino_diag_last_clock.argtypes = [c_int, c_void_p, POINTER(ctypes.c_ulonglong)]
     L.wino_conv3x3_small_plan.argtypes = [c_int] * 6 + [POINTER(c_int)] * 4
     L.wino_conv3x3_small_plan2.argtypes = [c_int] * 6 + [POINTER(c_int)] * 5
+    L.wino_debug_conv1x1_models.argtypes = [c_long, c_int, c_int, c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double)]
     L.wino_conv1x1_small_plan.argtypes = [c_long, c_int, c_int, c_int] + [POINTER(c_int)] * 3
     L.wino_conv1x1_small_plan2.argtypes = [c_long, c_int, c_int, c_int] + [POINTER(c_int)] * 5
     L.wino_conv3x3_plan_groups.argtypes = [c_int] * 6 + [POINTER(c_int)] * 4

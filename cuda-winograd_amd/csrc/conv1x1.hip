@@ -171,20 +171,19 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_f
 // pixel rows.  Every wave pulls its own operands through its CU's vector memory path and that path bounds the form.
 // Per workgroup (its 4 / KS blocks sit side by side): A = (4 / KS) * RT * 16 * Cin * 4 bytes of pixel rows (shared by
 // every column group, i.e. by all XCDs: fabric-side traffic), B = (4 / KS) * CT * 16 * Cin * 4 bytes of filter columns
-// (one XCD per column group: L2 hits).  Kernel times of every legal form at 1 .. 24 images of the four reference layers
-// (profiles/r3/latency_explore_1x1_forms.json, 330 points) fit
-//     T = 1.56 us + depth * (0.0289 us/KB * A + 0.0270 us/KB * B + 0.20 us),   depth = ceil(workgroups / CUs)
-// to 13 % on average; it underestimates launches several workgroups deep, so those must beat the tiled kernel's own
-// launch model (sk1_grid) by 20 %, one-deep launches just beat it.  Against the measured best of both kernels the rule
-// loses 3 % on average (at most 8 %) over those points.  M = 196: 1024->256 5.4 us against the tiled kernel's 19.3,
-// 512->128 3.8 / 10.5, 128->512 3.4 / 6.7, 256->1024 5.2 / 14.4; 8 images: 17.0 / 22.2, 6.8 / 12.0, 6.9 / 8.0, 18.5 / 20.0
-// (32 x 32 blocks: half the operand bytes per FLOP of 16 x 16).  WINO_1X1_ALGO=big|small and WINO_1X1_SMALL_KS / _RT /
-// _CT override.
+// (one XCD per column group: L2 hits), C = the block's outputs.  Kernel times of every legal form at 1 .. 24 images of the
+// four reference layers (tools/latency_cases.py explore1, profiles/r3/latency_explore_1x1_forms.json, 506 points) fit
+//     T = 2.16 us + depth * (0.0281 us/KB * A + 0.0141 (CT = 4: 0.0171) us/KB * B + 0.098 us/KB * C + 0.43 us),
+// depth = ceil(workgroups / CUs), to 13 % (least squares on the relative error); it underestimates launches several
+// workgroups deep, so those must beat the tiled kernel's own launch model (sk1_grid) by 20 %, one-deep launches by 7 %.  Picking by it costs 1.1 % on average against the best measured choice of both kernels at each of those points.
+// M = 196: 1024->256 5.4 us against the tiled kernel's 19.3, 512->128 3.8 / 10.5, 128->512 3.4 / 6.7, 256->1024 4.7 / 14.4;
+// 8 images: 14.6 / 22.1, 6.7 / 12.6, 7.4 / 8.6, 14.7 / 19.1 (32 x 64 blocks with 16-byte filter loads).
+// WINO_1X1_ALGO=big|small and WINO_1X1_SMALL_KS / _RT / _CT override.
 struct Small1Plan {
   bool use;
   int ks, rt, ct;
   long long wgs;
-  double t_us;
+  double t_us, t_big_us;   // the two launch models' times
 };
 static bool small1_legal(int Cin, int Kout, int ks, int rt, int ct) {
   (void)rt;
@@ -193,23 +192,25 @@ static bool small1_legal(int Cin, int Kout, int ks, int rt, int ct) {
 static double small1_time(long M, int Cin, int Kout, int cus, int ks, int rt, int ct, long long* wgs) {
   const long long rows = (M + 16 * rt - 1) / (16 * rt), cols = Kout / ((4 / ks) * ct * 16);
   *wgs = rows * cols;
+  // per workgroup: pixel KB, filter KB, output KB (one wave-quarter of each per wave)
   const double a_kb = (double)(4 / ks) * rt * 16.0 * Cin * 4.0 / 1e3, b_kb = (double)(4 / ks) * ct * 16.0 * Cin * 4.0 / 1e3;
+  const double c_kb = 16.0 * rt * (4 / ks) * ct * 16.0 * 4.0 / 1e3;
   const long long deep = (*wgs + cus - 1) / cus;
-  return 1.56 + (double)deep * (0.0289 * a_kb + 0.0270 * b_kb + 0.20);
+  return 2.16 + (double)deep * (0.0281 * a_kb + (ct == 4 ? 0.0171 : 0.0141) * b_kb + 0.098 * c_kb + 0.43);
 }
 static Small1Plan small1_plan(long M, int Cin, int Kout, int flags, int batch, int cus) {
-  Small1Plan pl = {false, 1, 1, 1, 0, 0.0};
+  Small1Plan pl = {false, 1, 1, 1, 0, 0.0, 0.0};
   if (batch != 1 || (flags & ~WINO_RELU) != 0 || M < 1) return pl;
   const Knobs kn = knobs();
   double best = 1e30;
   for (int rt = 1; rt <= 2; rt++)
-    for (int ct = 1; ct <= 2; ct++)
+    for (int ct = 1; ct <= 4; ct *= 2)
       for (int ks = 4; ks >= 1; ks >>= 1) {
         if (!small1_legal(Cin, Kout, ks, rt, ct)) continue;
         if (Cin / ks < 64 && ks > 1) continue;            // shorter K loops per wave are all overhead
         if ((kn.small_ks == 1 || kn.small_ks == 2 || kn.small_ks == 4) && ks != kn.small_ks) continue;
         if ((kn.small_rt == 1 || kn.small_rt == 2) && rt != kn.small_rt) continue;
-        if ((kn.small_ct == 1 || kn.small_ct == 2) && ct != kn.small_ct) continue;
+        if ((kn.small_ct == 1 || kn.small_ct == 2 || kn.small_ct == 4) && ct != kn.small_ct) continue;
         long long wgs = 0;
         const double t = small1_time(M, Cin, Kout, cus, ks, rt, ct, &wgs);
         const long long rows = (M + 16 * rt - 1) / (16 * rt);
@@ -222,7 +223,8 @@ static Small1Plan small1_plan(long M, int Cin, int Kout, int flags, int batch, i
     const bool four = four_waves(Cin, Kout);
     const int bn = four ? 64 : 128;
     (void)sk1_grid(((M + BM - 1) / BM) * (long long)(Kout / bn), Cin / 32, cus, Kout / bn, four, &t_big);
-    pl.use = best < (pl.wgs > cus ? 0.8 : 1.0) * t_big;
+    pl.t_big_us = t_big;
+    pl.use = best < (pl.wgs > cus ? 0.8 : 0.93) * t_big;   // (1024->256 at 40 images: modelled 38.5 / 41.0 us, measured 48.5 / 44.4)
   }
   if (kn.sk_1x1 != -1 || kn.sk_1x1_grid != 0) pl.use = false;   // a developer is forcing a form of the tiled kernel
   if (kn.algo_1x1 == 1) pl.use = false;
@@ -241,7 +243,9 @@ static int launch_1x1_small(const Small1Plan& pl, const float* A, const float* B
                             const float* bnScale, float* C, long M, int Cin, int Kout, int relu, hipStream_t s) {
   // x = column group, y = row block: see the kernel
   const dim3 grid((unsigned)(Kout / ((4 / pl.ks) * pl.ct * 16)), (unsigned)((M + 16 * pl.rt - 1) / (16 * pl.rt)));
-  if (pl.rt == 2 && pl.ct == 2) launch_1x1_small_ks<2, 2>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  if (pl.rt == 2 && pl.ct == 4) launch_1x1_small_ks<2, 4>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  else if (pl.ct == 4) launch_1x1_small_ks<1, 4>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  else if (pl.rt == 2 && pl.ct == 2) launch_1x1_small_ks<2, 2>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
   else if (pl.rt == 2) launch_1x1_small_ks<2, 1>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
   else if (pl.ct == 2) launch_1x1_small_ks<1, 2>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
   else launch_1x1_small_ks<1, 1>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
@@ -422,6 +426,14 @@ int wino_conv1x1_small_plan2(long M, int Cin, int Kout, int cus, int* use, int* 
   *row_tiles = pl.rt;
   *col_tiles = pl.ct;
   *workgroups = pl.use ? (int)pl.wgs : 0;
+  return WINO_OK;
+}
+
+int wino_debug_conv1x1_models(long M, int Cin, int Kout, int cus, double* t_latency_us, double* t_tiled_us) {
+  if (!t_latency_us || !t_tiled_us || cus < 1 || M < 1 || bad_1x1_dims(Cin, Kout)) { set_error("bad argument"); return WINO_E_ARG; }
+  const Small1Plan pl = small1_plan(M, Cin, Kout, 0, 1, cus);
+  *t_latency_us = pl.t_us;
+  *t_tiled_us = pl.t_big_us;
   return WINO_OK;
 }
 

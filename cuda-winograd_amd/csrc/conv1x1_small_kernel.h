@@ -20,6 +20,11 @@
 // 128 Cin bytes, a 32 x 32 block (RT = CT = 2: each fragment feeds two MFMA tiles) 256 Cin for four times the
 // output -- half the bytes per FLOP, which is what carries the form from a handful of images to a dozen
 // (conv1x1.hip: small1_plan).  Plain layers only (no padded operands, no residual).
+// CT = 4 is the WIDE form: a wave's 64 columns are cut into four tiles of STRIDED columns -- tile c = columns
+// n0 + 4 j + c, j = 0..15 -- so that lane (j, h) reads B[k][n0 + 4 j .. + 3] with ONE 16-byte load per k-step and uses
+// component c as tile c's operand: a quarter of the filter load instructions, each touching 8 whole cache lines (four
+// k-rows x 256 B) where the four-byte loads of the other forms touch 4 half lines per 256 B.  After the MFMAs register
+// r of tile c is column n0 + 16 h + 4 r + c: the four tiles' components r form 16-byte stores again.
 #pragma once
 #include "conv1x1_kernel.h"
 
@@ -32,9 +37,10 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
                      const float* __restrict__ bnBias, const float* __restrict__ bnScale,
                      float* __restrict__ Cout, long M, int Cin, int Kout, int relu) {
   static_assert(KS == 1 || KS == 2 || KS == 4, "waves per block");
-  static_assert((RT == 1 || RT == 2) && (CT == 1 || CT == 2), "MFMA tiles per wave");
+  static_assert((RT == 1 || RT == 2) && (CT == 1 || CT == 2 || CT == 4), "MFMA tiles per wave");
+  constexpr bool WIDE = CT == 4;           // strided column tiles, 16-byte filter loads
   constexpr int CB = 4 / KS;               // blocks per workgroup, side by side
-  constexpr int GS = RT * CT == 1 ? 8 : 4; // super-chunks per register buffer; two buffers in flight
+  constexpr int GS = RT * CT == 1 ? 8 : RT * CT >= 8 ? 2 : 4;   // super-chunks per register buffer; two buffers in flight
   constexpr int NT = RT * CT;
   __shared__ f32x4 red[4][NT][64];
   const int lane = threadIdx.x & 63;
@@ -55,11 +61,16 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
   const int kspan = Cin / KS;              // channels this wave contracts (a multiple of 16: checked on the host)
   const int nsc = kspan >> 4;
   // folded BN of this lane's out-channels: requested now, used at the very end
+  // (WIDE: sc[r] = the scales of columns n0 + 16 h + 4 r .. + 3, the four tiles' components r)
   f32x4 sc[CT], bi[CT];
 #pragma unroll
   for (int c = 0; c < CT; c++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) { sc[c][j] = bnScale[n0 + 16 * c + 4 * h + j]; bi[c][j] = bnBias[n0 + 16 * c + 4 * h + j]; }
+    for (int j = 0; j < 4; j++) {
+      const int col = WIDE ? n0 + 16 * h + 4 * c + j : n0 + 16 * c + 4 * h + j;
+      sc[c][j] = bnScale[col];
+      bi[c][j] = bnBias[col];
+    }
   const float* ap[RT];
 #pragma unroll
   for (int r = 0; r < RT; r++) {
@@ -67,7 +78,7 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
     m = m < M ? m : M - 1;                 // rows past the end read a valid row (never stored)
     ap[r] = A + m * Cin + kq * kspan + 4 * h;
   }
-  const float* bp = B + (size_t)(kq * kspan + 4 * h) * Kout + n0 + r16;
+  const float* bp = B + (size_t)(kq * kspan + 4 * h) * Kout + n0 + (WIDE ? 4 * r16 : r16);
 
   auto load_group = [&](int g, f32x4 (*a)[RT], float (*b)[CT][4]) {
 #pragma unroll
@@ -76,10 +87,19 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
       s = s < nsc ? s : nsc - 1;           // past the end: re-read the last one (never multiplied)
 #pragma unroll
       for (int r = 0; r < RT; r++) a[i][r] = *(const f32x4*)(ap[r] + s * 16);
+      if constexpr (WIDE) {
 #pragma unroll
-      for (int c = 0; c < CT; c++)
+        for (int jj = 0; jj < 4; jj++) {
+          const f32x4 w = *(const f32x4*)(bp + (size_t)(s * 16 + jj) * Kout);   // columns n0 + 4 r16 .. + 3 of k-row 16 s + 4 h + jj
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) b[i][c][jj] = bp[(size_t)(s * 16 + jj) * Kout + 16 * c];
+          for (int c = 0; c < 4; c++) b[i][c][jj] = w[c];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CT; c++)
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) b[i][c][jj] = bp[(size_t)(s * 16 + jj) * Kout + 16 * c];
+      }
     }
   };
   f32x4 acc[RT][CT];
@@ -141,12 +161,16 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
     const long row = m0 + 16 * r + r16;
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-      f32x4 val = sc[c] * acc[r][c] + bi[c];
+      // WIDE: c is the register index here: the four tiles' components c are columns n0 + 16 h + 4 c .. + 3
+      f32x4 val;
+      if constexpr (WIDE) val = (f32x4){acc[r][0][c], acc[r][1][c], acc[r][2][c], acc[r][3][c]};
+      else val = acc[r][c];
+      val = sc[c] * val + bi[c];
       if (relu) {
 #pragma unroll
         for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
       }
-      if (row < M) *(f32x4*)(Cout + row * Kout + n0 + 16 * c + 4 * h) = val;
+      if (row < M) *(f32x4*)(Cout + row * Kout + n0 + (WIDE ? 16 * h + 4 * c : 16 * c + 4 * h)) = val;
     }
   }
   if (clk) {

@@ -49,7 +49,7 @@ extern "C" {
  * wino_driver_set_gpu_alias, wino_driver_set_stdout_compat, wino_driver_cpu_baseline,
  * wino_diag_conv3x3_clock, wino_debug_tickets_in_use, wino_stream_check, wino_stream_reset_scratch,
  * wino_debug_poison_ticket, wino_diag_last_clock, wino_conv3x3_small_plan, wino_conv1x1_small_plan,
- * wino_conv3x3_plan_groups, wino_conv1x1_small_plan2, wino_conv3x3_small_plan2,
+ * wino_conv3x3_plan_groups, wino_conv1x1_small_plan2, wino_conv3x3_small_plan2, wino_debug_conv1x1_models,
  * WINO_E_STATE.  The library-owned stream-K scratch is never freed or moved while its
  * stream lives (it used to be reallocated when a larger shape arrived). */
 #define WINO_ABI_VERSION 1
@@ -262,6 +262,9 @@ int wino_conv1x1_small_plan(long M, int Cin, int Kout, int cus, int* use, int* k
  * 2 x 2 -- half the operand bytes per FLOP -- from a few images on). */
 int wino_conv1x1_small_plan2(long M, int Cin, int Kout, int cus, int* use, int* k_split, int* row_tiles, int* col_tiles,
                              int* workgroups);
+/* Host-side only (developer aid): the two launch models' times for this shape, the latency form's best candidate and the
+ * tiled kernel's, in microseconds; the latency form is taken while the first beats the second by the policy's margin. */
+int wino_debug_conv1x1_models(long M, int Cin, int Kout, int cus, double* t_latency_us, double* t_tiled_us);
 
 /* ---- ResNet bottleneck block of the 14x14 stage (BASELINE.json configs[4]) ---------
  * out = relu( bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x, w1))), U2))), w3)) + x )

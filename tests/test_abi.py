@@ -334,18 +334,19 @@ def test_latency_plans_at_the_reference_point(pkg, knobs):
     for (cin, kout), plan in want.items():
         assert pkg.small_plan_1x1_full(196, cin, kout, cus=256) == plan, (cin, kout)
     # where the tiled kernel takes over (images): measured crossovers, profiles/r3/latency_explore_1x1_forms.json
-    for (cin, kout), (last_small, first_big) in {(1024, 256): (8, 12), (512, 128): (16, 24), (128, 512): (8, 12),
-                                                 (256, 1024): (6, 8)}.items():
+    for (cin, kout), (last_small, first_big) in {(1024, 256): (16, 24), (512, 128): (24, 48), (128, 512): (8, 12),
+                                                 (256, 1024): (8, 12)}.items():
         assert pkg.small_plan_1x1(last_small * 196, cin, kout, cus=256)[0] == 1, (cin, kout, last_small)
         assert pkg.small_plan_1x1(first_big * 196, cin, kout, cus=256)[0] == 0, (cin, kout, first_big)
-    # from a few images on a wave holds 2 x 2 MFMA tiles (half the operand bytes per FLOP)
-    assert pkg.small_plan_1x1_full(8 * 196, 1024, 256, cus=256)[2:4] == (2, 2)
+    # from a few images on a wave holds 2 x 2, then 2 x 4 MFMA tiles (16-byte filter loads on strided column tiles)
+    assert pkg.small_plan_1x1_full(4 * 196, 1024, 256, cus=256)[2:4] == (2, 2)
+    assert pkg.small_plan_1x1_full(8 * 196, 1024, 256, cus=256)[2:4] == (2, 4)
     # every plan is a legal launch: the K-split divides Cin into whole 16-channel super-chunks, the workgroup's
     # column span divides Kout
     for cin, kout in ((32, 64), (96, 64), (160, 192), (2048, 64), (64, 448), (1024, 256)):
         for M in (1, 17, 196, 1000, 5000):
             use, ks, rt, ct, wgs = pkg.small_plan_1x1_full(M, cin, kout, cus=256)
-            assert cin % (16 * ks) == 0 and kout % ((4 // ks) * ct * 16) == 0 and rt in (1, 2) and ct in (1, 2), (cin, kout, M)
+            assert cin % (16 * ks) == 0 and kout % ((4 // ks) * ct * 16) == 0 and rt in (1, 2) and ct in (1, 2, 4), (cin, kout, M)
     assert pkg.small_plan_1x1(128 * 196, 1024, 256, cus=256)[0] == 0
     # a developer forcing a form of the tiled kernel gets the tiled kernel
     knobs.set("WINO_1X1_SK", "1")

@@ -154,7 +154,7 @@ def test_one_by_one_latency_forms_agree(M, Cin, Kout, relu, pkg, torch_dev, knob
     knobs.set("WINO_1X1_ALGO", "small")
     forms = 0
     for rt in (1, 2):
-        for ct in (1, 2):
+        for ct in (1, 2, 4):   # 4: strided column tiles, 16-byte filter loads
             for ks in (1, 2, 4):
                 if Cin % (16 * ks) or Kout % ((4 // ks) * ct * 16) or (Cin // ks < 64 and ks > 1):
                     continue

@@ -72,11 +72,14 @@ if mode == "explore1":   # the 1x1 latency form: every block shape and K-split a
         for N in (1, 2, 3, 4, 6, 8, 12, 16, 24):
             conv1(Cin, Kout, N)
             conv1(Cin, Kout, N, WINO_1X1_ALGO="big")
-            for rt, ct in ((1, 1), (2, 2), (1, 2), (2, 1)):
+            for rt, ct in ((1, 1), (2, 2), (1, 2), (2, 1), (1, 4), (2, 4)):
                 for ks in (4, 2, 1):
                     if Cin % (16 * ks) or Kout % ((4 // ks) * ct * 16) or (Cin // ks < 64 and ks > 1):
                         continue
                     if N >= 12 and (rt, ct) == (1, 1):
+                        continue
+                    wgs = -(-N * 196 // (16 * rt)) * (Kout // ((4 // ks) * ct * 16))
+                    if wgs > 2048:
                         continue
                     conv1(Cin, Kout, N, WINO_1X1_ALGO="small", WINO_1X1_SMALL_KS=ks, WINO_1X1_SMALL_RT=rt, WINO_1X1_SMALL_CT=ct)
     for c in cases:
@@ -131,7 +134,7 @@ for C in (256, 128):
             if 4 * sp <= (C // 16) * 2 and ((N * 49 + 15) // 16) * (C // (16 * ct)) * sp <= 512:
                 conv3(C, N, **small(ct, sp))
 for Cin, Kout in ((1024, 256), (512, 128), (128, 512), (256, 1024)):
-    for N in (1, 2, 3, 4, 6, 8, 12, 16) if mode == "full" else (1, 2, 4):
+    for N in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 40) if mode == "full" else (1, 2, 4):
         conv1(Cin, Kout, N)
         conv1(Cin, Kout, N, WINO_1X1_ALGO="big")
         conv1(Cin, Kout, N, WINO_1X1_ALGO="small")
