@@ -92,3 +92,21 @@ def test_fused_kernel_keeps_two_waves_per_simd(tmp_path):
     for name, v in k.items():
         assert v["vgprs"] <= 256 and v["occupancy"] >= 2 and v["spill"] == 0, (name, v)
         assert v["mfma"] == 128 and v["spill_code_in_mfma_blocks"] == 0 and v["sgpr_spill"] <= 80, (name, v)
+
+
+def test_latency_kernels_spill_nothing(tmp_path):
+    """The latency kernels run one wave per SIMD and may use the whole 512-register file -- the 16 x 64 form of the 3x3
+    kernel (128 accumulators + 128 filter-fragment registers + the staging buffer) does -- but a spill there is a
+    round trip to memory inside a loop that is bound by memory round trips: the first build of that form spilled 55
+    registers (DESIGN_NOTEBOOK section 3).  None may spill, and no spill code may sit beside MFMAs."""
+    k3 = {n: v for n, v in _compile_report("wino_f2_fused.hip", tmp_path).items() if "wino_f2_small_kernel" in n}
+    assert len(k3) == 3, sorted(k3)                # block widths 16 / 32 / 64
+    for name, v in k3.items():
+        assert v["spill"] == 0 and v["sgpr_spill"] == 0 and v["spill_code_in_mfma_blocks"] == 0, (name, v)
+        assert v["mfma"] >= 32, (name, v)
+    sub = tmp_path / "one"
+    sub.mkdir()
+    k1 = {n: v for n, v in _compile_report("conv1x1.hip", sub).items() if "conv1x1_small_kernel" in n}
+    assert len(k1) == 18, sorted(k1)               # KS {1, 2, 4} x RT {1, 2} x CT {1, 2, 4}
+    for name, v in k1.items():
+        assert v["spill"] == 0 and v["sgpr_spill"] == 0 and v["spill_code_in_mfma_blocks"] == 0, (name, v)
