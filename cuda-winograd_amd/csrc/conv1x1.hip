@@ -333,6 +333,7 @@ static int conv1x1_ex(const float* A, const float* B, const float* bnBias, const
                       wino_stream_t s) {
   if (!A || !B || !bnBias || !bnScale || !C) { set_error("NULL pointer"); return WINO_E_ARG; }
   if ((flags & WINO_ADD_RESIDUAL) && !residual) { set_error("WINO_ADD_RESIDUAL without residual"); return WINO_E_ARG; }
+  if (misaligned16(A, B, C, residual)) { set_error("tensor pointers must be 16-byte aligned"); return WINO_E_ARG; }
   if (flags & ~(WINO_RELU | WINO_A_PADDED | WINO_C_PADDED | WINO_ADD_RESIDUAL)) { set_error("unknown flag bits 0x%x", flags); return WINO_E_ARG; }
   if (M < 1 || bad_1x1_dims(Cin, Kout)) {
     set_error("unsupported 1x1 shape M=%ld Cin=%d Kout=%d (need Cin %% 32 == 0, Kout %% 64 == 0)",

@@ -1,6 +1,7 @@
 // Internal helpers shared by the HIP translation units of libwinograd_mi355x.so.
 // gfx950 (CDNA4, wave64) only.
 #pragma once
+#include <cstdint>
 
 #include <hip/hip_runtime.h>
 
@@ -16,6 +17,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Thread-local last-error text behind wino_last_error_string().
 void set_error(const char* fmt, ...);
+// Every tensor pointer of the C-ABI must be 16-byte aligned (the kernels move 16 bytes per lane; hipMalloc gives 256):
+// true if any of the given pointers is not.  BN vectors are read four bytes at a time and need no more than that.
+inline bool misaligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+           reinterpret_cast<uintptr_t>(d)) & 15u) != 0;
+}
 int hip_fail(hipError_t e, const char* what);
 // Stream-K scratch (wino_runtime.hip): write-through slabs for partial segments and ticket
 // counters, owned by the library, one set per (device, stream) so that launches on different

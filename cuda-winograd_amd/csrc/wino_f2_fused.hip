@@ -153,6 +153,7 @@ static int check_ck(int C, int K) {
 
 int wino_filter_transform_f2(const float* w_kcrs, float* U, int C, int K, wino_stream_t s) {
   if (!w_kcrs || !U) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if (misaligned16(U)) { set_error("tensor pointers must be 16-byte aligned"); return WINO_E_ARG; }
   if (int rc = check_ck(C, K)) return rc;
   const int n = C * K;
   hipLaunchKernelGGL(filter_transform_f2_kernel, dim3((n + 255) / 256), dim3(256), 0,
@@ -162,6 +163,7 @@ int wino_filter_transform_f2(const float* w_kcrs, float* U, int C, int K, wino_s
 
 int wino_filter_import_f4(const float* u36, float* U, int C, int K, wino_stream_t s) {
   if (!u36 || !U) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if (misaligned16(U)) { set_error("tensor pointers must be 16-byte aligned"); return WINO_E_ARG; }
   if (int rc = check_ck(C, K)) return rc;
   const int n = C * K;
   hipLaunchKernelGGL(filter_import_f4_kernel, dim3((n + 255) / 256), dim3(256), 0,
@@ -441,6 +443,7 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
 static int conv3x3_launch(const float* in, const float* U, const float* bnBias, const float* bnScale,
                           float* out, int N, int H, int W, int C, int K, int relu, hipStream_t s) {
   if (!in || !U || !bnBias || !bnScale || !out) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if (misaligned16(in, U, out)) { set_error("tensor pointers must be 16-byte aligned"); return WINO_E_ARG; }
   if (int rc = check_conv3x3_dims(H, W, C, K)) return rc;
   if (N < 1) { set_error("bad batch N=%d", N); return WINO_E_SHAPE; }
   long long step = conv3x3_batch_limit(H, W, C, K);

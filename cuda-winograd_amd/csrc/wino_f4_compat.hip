@@ -136,6 +136,7 @@ int wino_conv3x3_f4_bn_relu(const float* in, const float* u36, const float* bnBi
                             float* out, int N, int C, int K, int relu, void* workspace,
                             size_t workspace_bytes, wino_stream_t s) {
   if (!in || !u36 || !bnBias || !bnScale || !out || !workspace) { set_error("NULL pointer"); return WINO_E_ARG; }
+  if (misaligned16(in, u36, out, workspace)) { set_error("tensor pointers must be 16-byte aligned"); return WINO_E_ARG; }
   if (N < 1 || C <= 0 || K <= 0 || (C % 32) != 0 || (K % 64) != 0) {
     set_error("unsupported F(4x4) shape N=%d C=%d K=%d (need C %% 32 == 0, K %% 64 == 0)", N, C, K);
     return WINO_E_SHAPE;

@@ -58,7 +58,8 @@ enum {
   WINO_OK = 0,
   WINO_E_HIP = -1,       /* a HIP runtime call failed (no device, OOM, launch error) */
   WINO_E_SHAPE = -2,     /* unsupported / inconsistent shape argument */
-  WINO_E_ARG = -3,       /* NULL pointer, bad enum, workspace too small */
+  WINO_E_ARG = -3,       /* NULL pointer, bad enum, workspace too small, a tensor pointer that is not 16-byte aligned
+                            (the kernels move 16 bytes per lane; wino_malloc / hipMalloc give 256; BN vectors need 4) */
   WINO_E_STATE = -4,     /* the stream's library-owned scratch cannot be trusted (an earlier launch on it
                             failed or was aborted): wino_stream_reset_scratch() recovers */
 };

@@ -1007,6 +1007,26 @@ def test_bad_shapes_raise(pkg, torch_dev):
         pkg.conv1x1_bn(z(8, 48), z(48, 128), z(128), z(128), True)                 # Cin % 32
 
 
+def test_misaligned_tensor_pointers_are_refused(pkg, torch_dev):
+    """The kernels move 16 bytes per lane: a tensor pointer that is not 16-byte aligned (a view one float into a
+    buffer) is refused with WINO_E_ARG at the C-ABI instead of being handed to the loads."""
+    torch, dev = torch_dev
+    z = lambda n: torch.zeros(n, device=dev)
+    x, U, b, s, out = z(16 * 16 * 64 + 4), z(16 * 64 * 64 + 4), z(64), z(64), z(16 * 16 * 64 + 4)
+    L = pkg.lib()
+    args = lambda xo, uo, oo: (x.data_ptr() + xo, U.data_ptr() + uo, b.data_ptr(), s.data_ptr(), out.data_ptr() + oo, 1, 64, 64, 1, None)
+    assert L.wino_conv3x3_bn_relu(*args(0, 0, 0)) == 0
+    for off in ((4, 0, 0), (0, 8, 0), (0, 0, 12)):
+        assert L.wino_conv3x3_bn_relu(*args(*off)) == -3, off
+        assert b"16-byte aligned" in L.wino_last_error_string()
+    A, Bm, C = z(8 * 64 + 4), z(64 * 64 + 4), z(8 * 64 + 4)
+    one = lambda ao, bo, co: L.wino_conv1x1_bn(A.data_ptr() + ao, Bm.data_ptr() + bo, b.data_ptr(), s.data_ptr(), C.data_ptr() + co, 8, 64, 64, 1, None)
+    assert one(0, 0, 0) == 0
+    for off in ((4, 0, 0), (0, 4, 0), (0, 0, 4)):
+        assert one(*off) == -3, off
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------ the reference entry points
 LAYERS = ["kernel_128", "kernel_256", "kernel_128_1_in", "kernel_128_1_out", "kernel_256_1_in", "kernel_256_1_out"]
 
