@@ -141,7 +141,7 @@ def dist_init(backend: str, device=None):
 
 def timed_steps(step_fn, steps: int, warmup: int, sync_fn, barrier_fn) -> float:
     """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + sync on both
-    sides.  Returns this rank's elapsed seconds."""
+    sides.  Returns this rank's elapsed seconds (start barrier released -> its own last step synchronised)."""
     for _ in range(warmup):
         step_fn()
     sync_fn()
@@ -151,8 +151,8 @@ def timed_steps(step_fn, steps: int, warmup: int, sync_fn, barrier_fn) -> float:
     for _ in range(steps):
         step_fn()
     sync_fn()
-    barrier_fn()
-    t1 = time.perf_counter()
+    t1 = time.perf_counter()   # this rank's K steps are done; the MAX over ranks (max_over_ranks) is the job's time --
+    barrier_fn()               # the closing barrier's own latency (an all-reduce + host wake-up) is not a step
     return t1 - t0
 
 
