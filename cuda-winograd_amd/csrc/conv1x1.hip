@@ -167,8 +167,8 @@ static int sk1_grid(long long tiles, int nk, int cus, int nblk, bool four_wave_f
 }
 
 // The latency form (conv1x1_small_kernel.h): blocks of (16 RT) x (16 CT) outputs held by one wave, 4 waves per
-// workgroup, a block's K loop split over KS of them.  For plain layers (no padded operand, no residual) with few
-// pixel rows.  Every wave pulls its own operands through its CU's vector memory path and that path bounds the form.
+// workgroup, a block's K loop split over KS of them.  For layers with few pixel rows (plain or chained: padded operands,
+// residual).  Every wave pulls its own operands through its CU's vector memory path and that path bounds the form.
 // Per workgroup (its 4 / KS blocks sit side by side): A = (4 / KS) * RT * 16 * Cin * 4 bytes of pixel rows (shared by
 // every column group, i.e. by all XCDs: fabric-side traffic), B = (4 / KS) * CT * 16 * Cin * 4 bytes of filter columns
 // (one XCD per column group: L2 hits), C = the block's outputs.  Kernel times of every legal form at 1 .. 24 images of the
@@ -200,7 +200,8 @@ static double small1_time(long M, int Cin, int Kout, int cus, int ks, int rt, in
 }
 static Small1Plan small1_plan(long M, int Cin, int Kout, int flags, int batch, int cus) {
   Small1Plan pl = {false, 1, 1, 1, 0, 0.0, 0.0};
-  if (batch != 1 || (flags & ~WINO_RELU) != 0 || M < 1) return pl;
+  if (batch != 1 || M < 1) return pl;   // (every flag of the tiled kernel travels; batched launches do not)
+  (void)flags;
   const Knobs kn = knobs();
   double best = 1e30;
   for (int rt = 1; rt <= 2; rt++)
@@ -233,22 +234,23 @@ static Small1Plan small1_plan(long M, int Cin, int Kout, int flags, int batch, i
 }
 template <int RT, int CT>
 static void launch_1x1_small_ks(int ks, dim3 grid, hipStream_t s, const float* A, const float* B, const float* bnBias,
-                                const float* bnScale, float* C, long M, int Cin, int Kout, int relu) {
+                                const float* bnScale, const float* R, float* C, long M, int Cin, int Kout, int flags, PadGeo pg) {
   const dim3 block(256);
-  if (ks == 4) hipLaunchKernelGGL((conv1x1_small_kernel<4, RT, CT>), grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
-  else if (ks == 2) hipLaunchKernelGGL((conv1x1_small_kernel<2, RT, CT>), grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
-  else hipLaunchKernelGGL((conv1x1_small_kernel<1, RT, CT>), grid, block, 0, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  if (ks == 4) hipLaunchKernelGGL((conv1x1_small_kernel<4, RT, CT>), grid, block, 0, s, A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, pg);
+  else if (ks == 2) hipLaunchKernelGGL((conv1x1_small_kernel<2, RT, CT>), grid, block, 0, s, A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, pg);
+  else hipLaunchKernelGGL((conv1x1_small_kernel<1, RT, CT>), grid, block, 0, s, A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, pg);
 }
 static int launch_1x1_small(const Small1Plan& pl, const float* A, const float* B, const float* bnBias,
-                            const float* bnScale, float* C, long M, int Cin, int Kout, int relu, hipStream_t s) {
+                            const float* bnScale, const float* R, float* C, long M, int Cin, int Kout, int flags, PadGeo pg,
+                            hipStream_t s) {
   // x = column group, y = row block: see the kernel
   const dim3 grid((unsigned)(Kout / ((4 / pl.ks) * pl.ct * 16)), (unsigned)((M + 16 * pl.rt - 1) / (16 * pl.rt)));
-  if (pl.rt == 2 && pl.ct == 4) launch_1x1_small_ks<2, 4>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
-  else if (pl.ct == 4) launch_1x1_small_ks<1, 4>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
-  else if (pl.rt == 2 && pl.ct == 2) launch_1x1_small_ks<2, 2>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
-  else if (pl.rt == 2) launch_1x1_small_ks<2, 1>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
-  else if (pl.ct == 2) launch_1x1_small_ks<1, 2>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
-  else launch_1x1_small_ks<1, 1>(pl.ks, grid, s, A, B, bnBias, bnScale, C, M, Cin, Kout, relu);
+  if (pl.rt == 2 && pl.ct == 4) launch_1x1_small_ks<2, 4>(pl.ks, grid, s, A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, pg);
+  else if (pl.ct == 4) launch_1x1_small_ks<1, 4>(pl.ks, grid, s, A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, pg);
+  else if (pl.rt == 2 && pl.ct == 2) launch_1x1_small_ks<2, 2>(pl.ks, grid, s, A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, pg);
+  else if (pl.rt == 2) launch_1x1_small_ks<2, 1>(pl.ks, grid, s, A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, pg);
+  else if (pl.ct == 2) launch_1x1_small_ks<1, 2>(pl.ks, grid, s, A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, pg);
+  else launch_1x1_small_ks<1, 1>(pl.ks, grid, s, A, B, bnBias, bnScale, R, C, M, Cin, Kout, flags, pg);
   return launch_status("conv1x1_small_kernel");
 }
 
@@ -360,7 +362,7 @@ static int conv1x1_ex(const float* A, const float* B, const float* bnBias, const
     WINO_HIP(hipGetDevice(&dev));
     if (int rc = device_cus(dev, &cus)) return rc;
     const Small1Plan sp = small1_plan(M, Cin, Kout, flags, 1, cus);
-    if (sp.use) return launch_1x1_small(sp, A, B, bnBias, bnScale, C, M, Cin, Kout, (flags & WINO_RELU) != 0, (hipStream_t)s);
+    if (sp.use) return launch_1x1_small(sp, A, B, bnBias, bnScale, residual, C, M, Cin, Kout, flags, pg, (hipStream_t)s);
   }
   // BK = 32 keeps a workgroup at 60 KB of LDS, so two workgroups share a CU (4 waves per SIMD)
   // and one's prologue / barrier bubbles / store tail hide under the other's MFMAs; measured
@@ -449,8 +451,8 @@ int wino_conv1x1_prepare(long M, int Cin, int Kout, wino_stream_t s) {
   const long nMBl = (M + BM - 1) / BM;
   if (nMBl > (1L << 24)) { set_error("M too large"); return WINO_E_SHAPE; }
   const int nMB = (int)nMBl;
-  {   // (a plain layer small enough for the latency form uses no scratch; one that chains or adds a residual at
-      //  the same size takes the staged kernel, whose scratch is allocated below all the same)
+  {   // (a layer small enough for the latency form uses no scratch; the tiled kernel's is allocated below all the same:
+      //  a developer knob may still send the launch there)
     int dev = 0, cus = 0;
     WINO_HIP(hipGetDevice(&dev));
     if (int rc = device_cus(dev, &cus)) return rc;

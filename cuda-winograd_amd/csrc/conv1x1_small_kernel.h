@@ -19,7 +19,9 @@
 // The form is bound by the bytes every wave pulls through its CU's vector memory path: a 16 x 16 block costs
 // 128 Cin bytes, a 32 x 32 block (RT = CT = 2: each fragment feeds two MFMA tiles) 256 Cin for four times the
 // output -- half the bytes per FLOP, which is what carries the form from a handful of images to a dozen
-// (conv1x1.hip: small1_plan).  Plain layers only (no padded operands, no residual).
+// (conv1x1.hip: small1_plan).  The chained forms of the bottleneck block travel too (flags as in the tiled kernel:
+// WINO_A_PADDED / WINO_C_PADDED = the operand is the padded [N][H+2][W+2][.] tensor of the 3x3 layer, the output's zero
+// ring written by a flat pass over the grid; WINO_ADD_RESIDUAL = + residual before the ReLU), wave-uniform branches.
 // CT = 4 is the WIDE form: a wave's 64 columns are cut into four tiles of STRIDED columns -- tile c = columns
 // n0 + 4 j + c, j = 0..15 -- so that lane (j, h) reads B[k][n0 + 4 j .. + 3] with ONE 16-byte load per k-step and uses
 // component c as tile c's operand: a quarter of the filter load instructions, each touching 8 whole cache lines (four
@@ -35,7 +37,8 @@ template <int KS, int RT = 1, int CT = 1>
 __global__ void __launch_bounds__(256)
 conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
                      const float* __restrict__ bnBias, const float* __restrict__ bnScale,
-                     float* __restrict__ Cout, long M, int Cin, int Kout, int relu) {
+                     const float* __restrict__ Res, float* __restrict__ Cout, long M, int Cin, int Kout, int flags,
+                     const PadGeo pg) {
   static_assert(KS == 1 || KS == 2 || KS == 4, "waves per block");
   static_assert((RT == 1 || RT == 2) && (CT == 1 || CT == 2 || CT == 4), "MFMA tiles per wave");
   constexpr bool WIDE = CT == 4;           // strided column tiles, 16-byte filter loads
@@ -53,6 +56,26 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
     wino_clk_slot_1x1[1] = __builtin_amdgcn_s_memrealtime();
   }
   const int r16 = lane & 15, h = lane >> 4;
+  const bool relu = flags & WINO_RELU, a_padded = flags & WINO_A_PADDED, c_padded = flags & WINO_C_PADDED;
+  const bool add_res = flags & WINO_ADD_RESIDUAL;
+  if (c_padded) {
+    // ring pass: the padded output's zero ring (the 3x3 layer's padding) as a flat list of 16-byte units --
+    // images x ring pixels x Kout/4 units -- split over the grid (as in the tiled kernel)
+    const unsigned upp = (unsigned)Kout >> 2;
+    const unsigned rpx = 2 * pg.Wp + 2 * (pg.Hp - 2);   // ring pixels per image
+    const unsigned imgs = fastdiv((unsigned)M, pg.d_hw);
+    const unsigned long long U = (unsigned long long)imgs * rpx * upp;
+    const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y, bid = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned u_begin = (unsigned)(U * bid / nblk), u_end = (unsigned)(U * (bid + 1ull) / nblk);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned u = u_begin + threadIdx.x; u < u_end; u += 256) {
+      const unsigned pid = u / upp, unit = u - pid * upp;
+      const unsigned n = pid / rpx, qq = pid - n * rpx;
+      const unsigned y = qq < pg.Wp ? 0u : qq < 2 * pg.Wp ? pg.Hp - 1 : qq < 2 * pg.Wp + pg.Hp - 2 ? qq - 2 * pg.Wp + 1 : qq - 2 * pg.Wp - (pg.Hp - 2) + 1;
+      const unsigned x = qq < pg.Wp ? qq : qq < 2 * pg.Wp ? qq - pg.Wp : qq < 2 * pg.Wp + pg.Hp - 2 ? 0u : pg.Wp - 1;
+      *(f32x4*)(Cout + ((size_t)(n * pg.Hp + y) * pg.Wp + x) * Kout + unit * 4) = zero4;
+    }
+  }
   // blockIdx.x = column group: workgroups are dealt to the XCDs round-robin in x-fastest order, so the row blocks
   // that read one column slice of B share an XCD and its L2 (the column groups are a multiple of 8 for every
   // Kout % 128 == 0): B is then fetched once per launch instead of once per XCD
@@ -76,6 +99,7 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
   for (int r = 0; r < RT; r++) {
     long m = m0 + 16 * r + r16;
     m = m < M ? m : M - 1;                 // rows past the end read a valid row (never stored)
+    if (a_padded) m = padded_row(m, pg);
     ap[r] = A + m * Cin + kq * kspan + 4 * h;
   }
   const float* bp = B + (size_t)(kq * kspan + 4 * h) * Kout + n0 + (WIDE ? 4 * r16 : r16);
@@ -159,6 +183,7 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
 #pragma unroll
   for (int r = 0; r < RT; r++) {
     const long row = m0 + 16 * r + r16;
+    const long orow = c_padded && row < M ? padded_row(row, pg) : row;
 #pragma unroll
     for (int c = 0; c < CT; c++) {
       // WIDE: c is the register index here: the four tiles' components c are columns n0 + 16 h + 4 c .. + 3
@@ -166,11 +191,13 @@ conv1x1_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
       if constexpr (WIDE) val = (f32x4){acc[r][0][c], acc[r][1][c], acc[r][2][c], acc[r][3][c]};
       else val = acc[r][c];
       val = sc[c] * val + bi[c];
+      const int col = n0 + (WIDE ? 16 * h + 4 * c : 16 * c + 4 * h);
+      if (add_res && row < M) val += *(const f32x4*)(Res + row * Kout + col);   // the residual is never padded
       if (relu) {
 #pragma unroll
         for (int j = 0; j < 4; j++) val[j] = fmaxf(val[j], 0.f);
       }
-      if (row < M) *(f32x4*)(Cout + row * Kout + n0 + (WIDE ? 16 * h + 4 * c : 16 * c + 4 * h)) = val;
+      if (row < M) *(f32x4*)(Cout + orow * Kout + col) = val;
     }
   }
   if (clk) {

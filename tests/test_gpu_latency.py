@@ -172,6 +172,54 @@ def test_one_by_one_latency_forms_agree(M, Cin, Kout, relu, pkg, torch_dev, knob
     assert pkg.tickets_in_use() == 0
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Kout", [(1, 14, 14, 1024, 256), (2, 14, 14, 256, 1024), (3, 7, 7, 512, 128), (2, 5, 9, 96, 192),
+                                            (8, 14, 14, 256, 1024)])
+def test_one_by_one_latency_chained_forms(N, H, W, Cin, Kout, pkg, torch_dev, knobs):
+    """The bottleneck block's chaining layouts on the latency form: output into the interior of a
+    NaN-filled padded tensor with the ring written as exact zeros, input from a padded tensor whose ring holds garbage,
+    residual added before the ReLU -- every block shape against an fp64 GEMM and against the tiled kernel."""
+    torch, dev = torch_dev
+    g = torch.Generator(device="cpu").manual_seed(N * 1000 + Cin)
+    mk = lambda *s: ((torch.rand(*s, generator=g) - 0.5) * 2).to(dev)
+    A, Bm, b, s, R = mk(N, H, W, Cin), mk(Cin, Kout), mk(Kout), mk(Kout), mk(N * H * W, Kout)
+    Ap = (mk(N, H + 2, W + 2, Cin) * 100).contiguous()
+    Ap[:, 1:-1, 1:-1, :] = A
+    lin = (A.reshape(-1, Cin).double() @ Bm.double()) * s.double() + b.double()
+    want, want_res = torch.relu(lin), torch.relu(lin + R.double())
+    scale = float(want_res.abs().max())
+    ring = torch.ones(H + 2, W + 2, dtype=torch.bool, device=dev)
+    ring[1:-1, 1:-1] = False
+
+    def run(tag):
+        out = torch.full((N, H + 2, W + 2, Kout), float("nan"), device=dev)
+        pkg.conv1x1_bn_ex(A, Bm, b, s, pkg.RELU | pkg.C_PADDED, out=out, hw=(H, W))
+        assert bool((out[:, ring, :] == 0).all()), tag
+        assert float((out[:, 1:-1, 1:-1, :].reshape(-1, Kout).double() - want).abs().max()) < TIGHT * scale, tag
+        got2 = pkg.conv1x1_bn_ex(Ap, Bm, b, s, pkg.RELU | pkg.A_PADDED, hw=(H, W))
+        assert float((got2.reshape(-1, Kout).double() - want).abs().max()) < TIGHT * scale, tag
+        got3 = pkg.conv1x1_bn_ex(Ap, Bm, b, s, pkg.RELU | pkg.A_PADDED | pkg.ADD_RESIDUAL, residual=R, hw=(H, W))
+        assert float((got3.reshape(-1, Kout).double() - want_res).abs().max()) < TIGHT * scale, tag
+        return got3
+
+    knobs.set("WINO_1X1_ALGO", "big")
+    big = run("big")
+    knobs.set("WINO_1X1_ALGO", "small")
+    forms = 0
+    for rt, ct, ks in ((1, 1, 4), (1, 1, 1), (2, 2, 2), (1, 4, 4), (2, 4, 1), (2, 1, 2)):
+        if Cin % (16 * ks) or Kout % ((4 // ks) * ct * 16) or (Cin // ks < 64 and ks > 1):
+            continue
+        knobs.set("WINO_1X1_SMALL_KS", ks)
+        knobs.set("WINO_1X1_SMALL_RT", rt)
+        knobs.set("WINO_1X1_SMALL_CT", ct)
+        got = run((rt, ct, ks))
+        assert float((got - big).abs().max()) < 4e-6 * scale, (rt, ct, ks)
+        forms += 1
+    assert forms >= 1
+    for k in ("WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SMALL_RT", "WINO_1X1_SMALL_CT"):
+        knobs.unset(k)
+    run("auto")
+
+
 # ------------------------------------------------------------------ recovery after an aborted launch
 @pytest.mark.parametrize("kind", ["3x3 throughput", "3x3 latency", "3x3 latency wide", "1x1"])
 def test_a_dirty_ticket_counter_is_reported_and_reset_recovers(kind, pkg, torch_dev, knobs):

@@ -66,7 +66,34 @@ def conv1(Cin, Kout, N, **kw):
     knob()
 
 
+def block(N, **kw):
+    """The bottleneck block 1024 -> 256 -> 256 -> 1024 (3 launches per call)."""
+    C4, Cm = 1024, 256
+    x = (torch.rand(N, 14, 14, C4) - 0.5).to(dev)
+    w1, w3 = ((torch.rand(C4, Cm) - 0.5) / 8).to(dev), ((torch.rand(Cm, C4) - 0.5) / 4).to(dev)
+    U2 = pkg.filter_transform_f2(((torch.rand(Cm, Cm, 3, 3) - 0.5) / 12).to(dev))
+    bn = [((torch.rand(c) - 0.5).to(dev), (torch.rand(c) + 0.5).to(dev)) for c in (Cm, Cm, C4)]
+    out = torch.empty(N, 14, 14, C4, device=dev)
+    ws = torch.empty(pkg.lib().wino_residual_block_workspace_bytes_hw(N, 14, 14, Cm) // 4, device=dev)
+    torch.cuda.synchronize()
+    knob(**kw)
+    tag = " ".join("%s=%s" % (k.replace("WINO_", "").lower(), v) for k, v in kw.items()) or "auto"
+    for _ in range(REPS):
+        pkg.residual_block(x, w1, bn[0], U2, bn[1], w3, bn[2], out=out, workspace=ws)
+    torch.cuda.synchronize()
+    cases.append({"case": "block 1024->256->256->1024 N=%d [%s]" % (N, tag), "launches": 3 * REPS, "per_call": 3})
+    knob()
+
+
 small = lambda ct, sp: dict(WINO_3X3_ALGO="small", WINO_SMALL_CT=ct, WINO_SMALL_SPLIT=sp)
+if mode == "block":
+    for N in (1, 2, 4, 8, 16, 32):
+        block(N)
+        block(N, WINO_1X1_ALGO="big")
+        block(N, WINO_1X1_ALGO="big", WINO_3X3_ALGO="big")
+    for c in cases:
+        print(json.dumps(c), flush=True)
+    sys.exit(0)
 if mode == "explore1":   # the 1x1 latency form: every block shape and K-split against the tiled kernel
     for Cin, Kout in ((1024, 256), (512, 128), (128, 512), (256, 1024)):
         for N in (1, 2, 3, 4, 6, 8, 12, 16, 24):

@@ -27,7 +27,8 @@ for c in cases:
     i += c["launches"]
     if not chunk:
         break
-    d = [(e - s) / 1e3 for s, e, *_ in chunk[10:]]        # the first ten launches of a case are its warm-up
+    pc = c.get("per_call", 1)                              # launches per call (the bottleneck block: 3): durations summed per call
+    d = [sum((e - s) / 1e3 for s, e, *_ in chunk[j:j + pc]) for j in range(10 * pc, len(chunk) - pc + 1, pc)]   # the first ten calls of a case are its warm-up
     gap = [(chunk[j + 1][0] - chunk[j][1]) / 1e3 for j in range(10, len(chunk) - 1)]
     name = chunk[-1][2]
     short = next(h for h in HOT if h in name) + (name[name.index("<"):name.index(">") + 1] if "<" in name else "")
