@@ -327,7 +327,7 @@ static int check_conv3x3(int N, int H, int W, int C, int K) {
 
 // Two kernels, same arithmetic: the throughput kernel (64-tile x 64-out-channel items, 8-wave
 // workgroups, whole-item rounds + stream-K tail) and the one-wave-per-SIMD latency kernel (blocks of 16 tiles
-// x 16 CT out-channels, CT = 1, 2 or 4; 14x14 maps only; wino_f2_small_kernel.h), which wins while its blocks fit
+// x 16 CT out-channels, CT = 1, 2 or 4; any feature map; wino_f2_small_kernel.h), which wins while its blocks fit
 // ONE round of the CUs (a second round of blocks doubles the latency kernel's time at once).
 // While the blocks leave CUs idle the latency kernel also splits a block's contraction over S workgroups
 // (C-split): S as large as the idle CUs allow (at most 8, and every wave of the S workgroups gets a task in the
@@ -350,10 +350,10 @@ struct SmallPlan {
 // round trip, growing with the block) 0.4 / 1.2 / 4.5 us at CT = 1 / 2 / 4.  148 measured forms, rms 0.85 us.
 constexpr double SMALL_T0 = 5.70, SMALL_ROUND = 0.487, SMALL_FLT = 0.509, SMALL_FLT_FILL = 0.2285;
 // The block width ct on `cus` CUs: its blocks and the C-split.  false if its blocks do not fit one round.
-static bool small_form(int N, int C, int K, int cus, int ct, SmallPlan* pl) {
+static bool small_form(int N, int tiles, int C, int K, int cus, int ct, SmallPlan* pl) {
   if ((K % (16 * ct)) != 0) return false;
   pl->ct = ct;
-  pl->nT16 = (int)(((long long)N * WINO_TILES + 15) / 16);
+  pl->nT16 = (int)(((long long)N * tiles + 15) / 16);
   const long long blocks = (long long)pl->nT16 * (K / (16 * ct));
   pl->blocks = (size_t)blocks;
   pl->split = 1;
@@ -372,20 +372,23 @@ static bool small_form(int N, int C, int K, int cus, int ct, SmallPlan* pl) {
 }
 static SmallPlan small_plan(int N, int H, int W, int C, int K, int cus) {
   SmallPlan pl = {false, 1, 0, 0, 1, 0.0};
-  if (H != WINO_PQ || W != WINO_PQ || (C % 16) != 0) return pl;
+  if ((C % 16) != 0 || H < 1 || W < 1) return pl;
+  const long long tiles_ll = (long long)((H + 1) / 2) * ((W + 1) / 2);
+  if (tiles_ll * N > (1ll << 30)) return pl;
+  const int tiles = (int)tiles_ll;
   const Knobs kn = knobs();
   if (kn.small3_ct == 1 || kn.small3_ct == 2 || kn.small3_ct == 4) {
-    pl.use = small_form(N, C, K, cus, kn.small3_ct, &pl);
+    pl.use = small_form(N, tiles, C, K, cus, kn.small3_ct, &pl);
   } else {
     SmallPlan best = pl;
     for (int ct = 1; ct <= 4; ct *= 2) {
       SmallPlan f = pl;
-      if (small_form(N, C, K, cus, ct, &f) && (!best.use || f.t_us < best.t_us)) { best = f; best.use = true; }
+      if (small_form(N, tiles, C, K, cus, ct, &f) && (!best.use || f.t_us < best.t_us)) { best = f; best.use = true; }
     }
-    const double items = (double)((N * WINO_TILES + TB - 1) / TB) * (K / KB);
+    const double items = (double)(((long long)N * tiles + TB - 1) / TB) * (K / KB);
     const double t_big = 18.8 + 0.0174 * C + 1.94 * items * (C / BC) / cus;
     if (best.use && 1.08 * best.t_us < t_big) pl = best;   // (the margin: the model is 2-3 us short on a full round of wide blocks)
-    else small_form(N, C, K, cus, 1, &pl), pl.use = false;   // (the counts a forced launch would use)
+    else small_form(N, tiles, C, K, cus, 1, &pl), pl.use = false;   // (the counts a forced launch would use)
   }
   if (kn.algo_3x3 == 1) pl.use = false;
   if (kn.algo_3x3 == 2) pl.use = pl.nT16 <= 65535 && (K % (16 * pl.ct)) == 0;
@@ -469,11 +472,19 @@ static int conv3x3_launch_one(const float* in, const float* U, const float* bnBi
   if (sp.use) {
     SkBufs bufs;
     if (int rc = small_scratch(dev, s, sp, &bufs)) return rc;
-    const SmallParams prm = {in, U, bnBias, bnScale, out, N, C, K, relu, bufs.slabs, bufs.tickets, bufs.err, nullptr};
+    const unsigned stx = (unsigned)((W + 1) / 2), st = (unsigned)((H + 1) / 2) * stx;
+    const Geo sgeo = {H + 2, W + 2, st, stx, make_fastdiv(st), make_fastdiv(stx)};
+    const SmallParams prm = {in, U, bnBias, bnScale, out, N, C, K, relu, bufs.slabs, bufs.tickets, bufs.err, nullptr, sgeo};
     const dim3 grid(K / (16 * sp.ct), sp.nT16, sp.split), block(64 * SMALL_WAVES);   // x = out-channel block: see the kernel
-    if (sp.ct == 4) hipLaunchKernelGGL(wino_f2_small_kernel<4>, grid, block, 0, s, prm);
-    else if (sp.ct == 2) hipLaunchKernelGGL(wino_f2_small_kernel<2>, grid, block, 0, s, prm);
-    else hipLaunchKernelGGL(wino_f2_small_kernel<1>, grid, block, 0, s, prm);
+    if (fixed14) {
+      if (sp.ct == 4) hipLaunchKernelGGL((wino_f2_small_kernel<4, false>), grid, block, 0, s, prm);
+      else if (sp.ct == 2) hipLaunchKernelGGL((wino_f2_small_kernel<2, false>), grid, block, 0, s, prm);
+      else hipLaunchKernelGGL((wino_f2_small_kernel<1, false>), grid, block, 0, s, prm);
+    } else {
+      if (sp.ct == 4) hipLaunchKernelGGL((wino_f2_small_kernel<4, true>), grid, block, 0, s, prm);
+      else if (sp.ct == 2) hipLaunchKernelGGL((wino_f2_small_kernel<2, true>), grid, block, 0, s, prm);
+      else hipLaunchKernelGGL((wino_f2_small_kernel<1, true>), grid, block, 0, s, prm);
+    }
     const int rc = launch_status("wino_f2_small_kernel");
     if (rc && sp.split > 1) sk_mark_failed(dev, s);
     return rc;

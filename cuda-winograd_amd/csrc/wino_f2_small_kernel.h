@@ -49,7 +49,10 @@
 //      throughput kernel (wino_f2_fused_kernel.h).
 // The MFMA's A operand is the filter fragment and its B operand the transformed pixels, so a lane ends up with
 // four CONSECUTIVE out-channels of one tile: BN with four scales, 16-byte stores.
-// Requires C % 16 == 0 and the 14x14 map (the dispatcher takes the throughput kernel otherwise).
+// Requires C % 16 == 0.  GEN = false is the reference's 14x14 map (geometry folded into the code); GEN = true carries the
+// feature map in the arguments (ResNet's other stages): tile decode by multipliers, patch rows /
+// columns of a clipped last tile row / column clamped into the tensor (a Winograd output depends on its own 3x3 window
+// only, so the kept outputs are unaffected), surplus outputs not stored, the zero ring by a flat pass over the grid.
 // Same arithmetic, same packed filter buffer and same output contract as the big kernel.
 #pragma once
 #include "wino_f2_fused_kernel.h"
@@ -72,12 +75,13 @@ struct SmallParams {
   unsigned* tickets;         // [block]
   unsigned* err;             // host-visible word: set when a ticket counter was found dirty (S > 1 only)
   unsigned long long* dbg;   // timeline build only (DIAG, tools/small_timeline): 8 stamps per workgroup
+  Geo geo;                   // GEN = true only: the feature map (other than the reference's 14 x 14)
 };
 
 // DIAG = true is the timeline build (tools/small_timeline.hip): wave 0 of every workgroup stores s_memrealtime
 // (100 MHz, chip-wide) at entry, first stage in LDS, MFMAs done, LDS level done, slab drained, ticket drawn, gather
 // landed, exit.  The product kernel is DIAG = false.
-template <int CT, bool DIAG = false>
+template <int CT, bool GEN = false, bool DIAG = false>
 __global__ void __launch_bounds__(64 * SMALL_WAVES)
 wino_f2_small_kernel(const SmallParams prm) {
   static_assert(CT == 1 || CT == 2 || CT == 4, "MFMA tiles per wave");
@@ -111,7 +115,28 @@ wino_f2_small_kernel(const SmallParams prm) {
       wino_clk_slot_3x3[3] = __builtin_amdgcn_s_memrealtime();
     }
   };
-  const int totalTiles = N * WINO_TILES;
+  const Geo geo = prm.geo;
+  const int Hp = GEN ? geo.Hp : WINO_HW, Wp = GEN ? geo.Wp : WINO_HW;
+  if constexpr (GEN) {
+    // ring pass: the output's zero ring (the next 3x3 layer's padding) as a flat list of 16-byte units -- images x ring
+    // pixels x K/4 units -- split over the grid (the 14x14 build writes each tile's share with the tile, below)
+    const unsigned upp = (unsigned)K >> 2;
+    const unsigned rpx = 2u * Wp + 2u * (Hp - 2);       // ring pixels per image
+    const unsigned long long U = (unsigned long long)N * rpx * upp;
+    const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y * gridDim.z;
+    const unsigned long long bid = ((unsigned long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned u_begin = (unsigned)(U * bid / nblk), u_end = (unsigned)(U * (bid + 1ull) / nblk);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned u = u_begin + threadIdx.x; u < u_end; u += 64 * SMALL_WAVES) {
+      const unsigned pid = u / upp, unit = u - pid * upp;
+      const unsigned n = pid / rpx, qq = pid - n * rpx;
+      const unsigned uW = (unsigned)Wp, uH = (unsigned)Hp;
+      const unsigned y = qq < uW ? 0u : qq < 2 * uW ? uH - 1 : qq < 2 * uW + uH - 2 ? qq - 2 * uW + 1 : qq - 2 * uW - (uH - 2) + 1;
+      const unsigned x = qq < uW ? qq : qq < 2 * uW ? qq - uW : qq < 2 * uW + uH - 2 ? 0u : uW - 1;
+      *(f32x4*)(prm.out + ((size_t)(n * uH + y) * uW + x) * K + unit * 4) = zero4;
+    }
+  }
+  const int totalTiles = N * (GEN ? (int)geo.tiles : WINO_TILES);
   const int KBLK = K >> 6;
   // Round r of workgroup `split` = tasks 4 (split + r S) + q, q = 0..3: super-chunks sc0 = 2 (split + r S) and sc0 + 1
   // (32 consecutive channels), row groups 0 and 1 of each.  Wave q: super-chunk sc0 + (q >> 1), row group q & 1.
@@ -126,17 +151,29 @@ wino_f2_small_kernel(const SmallParams prm) {
   const int px_l = lane >> 3, u_l = lane & 7;
   const float* a_tile[4];
   unsigned w_off[4];                                    // LDS byte offset of this lane's unit in px half 0
+  int e_off[GEN ? 4 : 1][2];                            // this lane's element offset inside a tile's patch, px half 0 / 1
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int T = 4 * q + j;
     int g = tb16 * 16 + T;
     g = g < totalTiles ? g : totalTiles - 1;
-    const TileCoord tc = decode_tile(g);
-    a_tile[j] = in + ((size_t)(tc.n * WINO_HW + 2 * tc.ty) * WINO_HW + 2 * tc.tx) * C;
+    const TileCoord tc = decode_tile_g<GEN>(g, geo);
+    a_tile[j] = in + ((size_t)(tc.n * Hp + 2 * tc.ty) * Wp + 2 * tc.tx) * C;
     w_off[j] = (unsigned)((T * 16 + (px_l ^ (T & 1))) * 128 + ((u_l ^ ((T >> 1) & 7)) << 4));
+    if constexpr (GEN) {
+      // odd H or W: the last tile row / column reaches one row / column past the padded tensor -- clamp into it
+      const int col = 2 * tc.tx + (px_l & 3), colc = (col < Wp ? col : Wp - 1) - 2 * tc.tx;
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        const int row = 2 * tc.ty + 2 * hf + (px_l >> 2), rowc = (row < Hp ? row : Hp - 1) - 2 * tc.ty;
+        e_off[j][hf] = (rowc * Wp + colc) * C;
+      }
+    }
   }
-  // this lane's element offset inside a tile's patch for px half 0 / 1 (px = 8 half + px_l: row 2 half + (px_l >> 2))
-  const int e_off0 = ((px_l >> 2) * WINO_HW + (px_l & 3)) * C, e_off1 = e_off0 + 2 * WINO_HW * C;
+  if constexpr (!GEN) {   // (px = 8 half + px_l: row 2 half + (px_l >> 2))
+    e_off[0][0] = ((px_l >> 2) * WINO_HW + (px_l & 3)) * C;
+    e_off[0][1] = e_off[0][0] + 2 * WINO_HW * C;
+  }
   f32x4 stg[8];
   auto load_a = [&](int r) {
     const int sc0 = 2 * (split + r * S);
@@ -146,8 +183,8 @@ wino_f2_small_kernel(const SmallParams prm) {
     const int c_off = sc * 16 + (u_l & 3) * 4;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      stg[2 * j] = *(const f32x4*)(a_tile[j] + e_off0 + c_off);
-      stg[2 * j + 1] = *(const f32x4*)(a_tile[j] + e_off1 + c_off);
+      stg[2 * j] = *(const f32x4*)(a_tile[j] + e_off[GEN ? j : 0][0] + c_off);
+      stg[2 * j + 1] = *(const f32x4*)(a_tile[j] + e_off[GEN ? j : 0][1] + c_off);
     }
   };
   auto store_a = [&](int stage) {
@@ -348,11 +385,11 @@ wino_f2_small_kernel(const SmallParams prm) {
   float* __restrict__ out = prm.out;
   const int relu = prm.relu;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const TileCoord tc = decode_tile(gt);
+  const TileCoord tc = decode_tile_g<GEN>(gt, geo);
   const int oy = 1 + 2 * tc.ty, ox = 1 + 2 * tc.tx;
 #pragma unroll
   for (int c = 0; c < CT; c++) {
-    float* o = out + (size_t)tc.n * WINO_HW * WINO_HW * K + (kqq * CT + c) * 16 + 4 * h;
+    float* o = out + (size_t)tc.n * Hp * Wp * K + (kqq * CT + c) * 16 + 4 * h;
 #pragma unroll
     for (int pp = 0; pp < 4; pp++) {
       f32x4 val = {y[c][0][pp], y[c][1][pp], y[c][2][pp], y[c][3][pp]};
@@ -361,8 +398,11 @@ wino_f2_small_kernel(const SmallParams prm) {
 #pragma unroll
         for (int r = 0; r < 4; r++) val[r] = fmaxf(val[r], 0.f);
       }
-      *(f32x4*)(o + (size_t)((oy + (pp >> 1)) * WINO_HW + ox + (pp & 1)) * K) = val;
+      // (odd H or W: the last tile row / column computes one output row / column too many; it must not reach the ring)
+      if (!GEN || (oy + (pp >> 1) <= Hp - 2 && ox + (pp & 1) <= Wp - 2))
+        *(f32x4*)(o + (size_t)((oy + (pp >> 1)) * Wp + ox + (pp & 1)) * K) = val;
     }
+    if constexpr (GEN) continue;   // (the ring pass at the top wrote the ring)
     // zero ring (the next 3x3 layer's padding, Kernel128_winograd.cu:163,243)
     if (tc.ty == 0) {
       *(f32x4*)(o + (size_t)(ox)*K) = zero4;

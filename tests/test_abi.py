@@ -319,7 +319,8 @@ def test_latency_plans_at_the_reference_point(pkg, knobs):
     assert pkg.small_plan_3x3_full(41, 128, 128, cus=256)[:4] == (1, 2, 1, 4) and pkg.small_plan_3x3(42, 128, 128, cus=256)[0] == 0
     assert pkg.small_plan_3x3(10, 384, 384, cus=256)[0] == 0               # a full round of wide blocks at 384 channels loses
     assert pkg.small_plan_3x3(1, 24, 64, cus=256)[0] == 0                  # C % 16: throughput kernel only
-    assert pkg.small_plan_3x3(1, 256, 256, cus=256, H=28, W=28)[0] == 0    # 14x14 only
+    assert pkg.small_plan_3x3_full(1, 128, 128, cus=256, H=28, W=28)[:4] == (1, 2, 2, 1)   # other feature maps: 196 tiles = 4 images' worth
+    assert pkg.small_plan_3x3_full(1, 512, 512, cus=256, H=7, W=7)[:4] == (1, 2, 8, 1)                 # one block of 16 tiles x 32 k-blocks x 8 splits
     # every wave of the S workgroups gets a task: 4 S <= (C / 16) * (4 / PR)
     for C in (16, 32, 48, 64, 96, 128, 192, 256, 384, 512):
         for N in (1, 2, 3, 5):

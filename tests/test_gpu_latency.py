@@ -80,6 +80,57 @@ def test_conv3x3_latency_forms_agree(N, C, K, pkg, O, torch_dev, knobs):
     assert pkg.tickets_in_use() == 0
 
 
+@pytest.mark.parametrize("N,H,W,C,K", [(1, 7, 7, 512, 512), (1, 28, 28, 128, 128), (1, 56, 56, 64, 64), (2, 5, 9, 32, 64),
+                                       (3, 1, 1, 16, 64), (1, 13, 15, 48, 128), (2, 8, 12, 16, 64), (1, 2, 2, 16, 192)])
+def test_conv3x3_latency_other_feature_maps(N, H, W, C, K, pkg, O, torch_dev, knobs):
+    """the latency kernel with the geometry in its arguments (ResNet's 56x56, 28x28 and 7x7
+    stages at one image, odd sizes whose last tile row / column is clipped, a single tile or pixel): every block width
+    and split on NaN-filled [N][H+2][W+2][K] outputs -- interior against the fp64 oracle, ring exact zeros, bitwise
+    repeatable, counters at zero -- and the automatic choice."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(H * 131 + W + C)
+    x = (rng.rand(N, H + 2, W + 2, C) - 0.5).astype(np.float32)
+    w = (rng.rand(K, C, 3, 3) - 0.5).astype(np.float32)
+    s = (rng.rand(K) - 0.5).astype(np.float32)
+    b = (rng.rand(K) - 0.5).astype(np.float32)
+    xt, wt, st, bt = (torch.from_numpy(a).to(dev) for a in (x, w, s, b))
+    U = pkg.filter_transform_f2(wt)
+    want = O.conv3x3_bn_relu_direct(x, w, s, b)
+    scale = float(np.abs(want).max())
+    ring = np.ones((H + 2, W + 2), bool)
+    ring[1:H + 1, 1:W + 1] = False
+    tiles = ((H + 1) // 2) * ((W + 1) // 2)
+    knobs.set("WINO_3X3_ALGO", "small")
+    ref = None
+    for ct in (1, 2, 4):
+        if K % (16 * ct):
+            continue
+        knobs.set("WINO_SMALL_CT", ct)
+        for sp in (1, 2, 4, 8):
+            if sp > 1 and 4 * sp > (C // 16) * 2:
+                continue
+            knobs.set("WINO_SMALL_SPLIT", sp)
+            use, gpr, gsp, gct, wgs = pkg.small_plan_3x3_full(N, C, K, H=H, W=W)
+            assert (use, gsp, gct) == (1, sp, ct) and wgs == -(-N * tiles // 16) * (K // (16 * ct)) * sp, (ct, sp)
+            out = torch.full((N, H + 2, W + 2, K), float("nan"), device=dev)
+            pkg.conv3x3_bn_relu(xt, U, bt, st, out=out)
+            assert pkg.tickets_in_use() == 0, (ct, sp)
+            got = out.cpu().numpy()
+            assert not np.isnan(got).any(), (ct, sp)
+            assert O.rel_error(got, want) < TIGHT, (ct, sp, O.rel_error(got, want))
+            assert (got[:, ring, :] == 0).all(), (ct, sp)
+            assert torch.equal(pkg.conv3x3_bn_relu(xt, U, bt, st), out), (ct, sp)
+            if ref is None:
+                ref = out
+            assert float((out - ref).abs().max()) < 4e-6 * scale, (ct, sp)
+    for k in ("WINO_SMALL_CT", "WINO_SMALL_SPLIT", "WINO_3X3_ALGO"):
+        knobs.unset(k)
+    assert ref is not None
+    auto = pkg.conv3x3_bn_relu(xt, U, bt, st)
+    assert float((auto - ref).abs().max()) < 4e-6 * scale
+    assert pkg.tickets_in_use() == 0
+
+
 def test_conv3x3_latency_with_a_competing_stream(pkg, torch_dev, knobs):
     """Split blocks while a second stream's launches hold CUs: the S workgroups of a block then start at
     different times and any of them may be the finisher.  Bitwise equal results, counters at zero."""

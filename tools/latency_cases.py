@@ -37,18 +37,19 @@ def run(name, fn):
     cases.append({"case": name, "launches": REPS})
 
 
-def conv3(C, N, **kw):
+def conv3(C, N, HW=14, **kw):
     w = (torch.rand(C, C, 3, 3) - 0.5).to(dev)
     s, b = (torch.rand(C) - 0.5).to(dev), (torch.rand(C) - 0.5).to(dev)
     U = pkg.filter_transform_f2(w)
-    x = (torch.rand(N, 16, 16, C) - 0.5).to(dev)
-    out = torch.empty(N, 16, 16, C, device=dev)
+    x = (torch.rand(N, HW + 2, HW + 2, C) - 0.5).to(dev)
+    out = torch.empty(N, HW + 2, HW + 2, C, device=dev)
     torch.cuda.synchronize()
     knob(**kw)
     tag = " ".join("%s=%s" % (k.replace("WINO_", "").lower(), v) for k, v in kw.items()) or "auto"
-    use, pr, sp, ct, wgs = pkg.small_plan_3x3_full(N, C, C)
+    use, pr, sp, ct, wgs = pkg.small_plan_3x3_full(N, C, C, H=HW, W=HW)
     form = "small 1x%d pr%d s%d %d wgs" % (ct, pr, sp, wgs) if use else "big"
-    run("3x3 C=%d N=%d [%s -> %s]" % (C, N, tag, form), lambda: pkg.conv3x3_bn_relu(x, U, b, s, out=out))
+    size = "" if HW == 14 else " %dx%d" % (HW, HW)
+    run("3x3%s C=%d N=%d [%s -> %s]" % (size, C, N, tag, form), lambda: pkg.conv3x3_bn_relu(x, U, b, s, out=out))
     knob()
 
 
@@ -86,6 +87,14 @@ def block(N, **kw):
 
 
 small = lambda ct, sp: dict(WINO_3X3_ALGO="small", WINO_SMALL_CT=ct, WINO_SMALL_SPLIT=sp)
+if mode == "stages":   # ResNet's four 3x3 stages at small batches: the latency kernel against the throughput kernel
+    for HW, C in ((56, 64), (28, 128), (14, 256), (7, 512)):
+        for N in (1, 2, 4, 8):
+            conv3(C, N, HW)
+            conv3(C, N, HW, WINO_3X3_ALGO="big")
+    for c in cases:
+        print(json.dumps(c), flush=True)
+    sys.exit(0)
 if mode == "block":
     for N in (1, 2, 4, 8, 16, 32):
         block(N)

@@ -26,8 +26,8 @@ static void run(int C, int N, int S) {
   CK(hipMemcpy(U, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(in, h.data(), (size_t)N * 256 * C * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b, h.data(), K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s, h.data() + K, K * 4, hipMemcpyHostToDevice));
-  const SmallParams prm = {in, U, b, s, out, N, C, K, 1, slabs, tickets, err, dbg};
-  for (int i = 0; i < 200; i++) hipLaunchKernelGGL((wino_f2_small_kernel<CT, true>), dim3(K / (16 * CT), nT16, S), dim3(256), 0, 0, prm);
+  const SmallParams prm = {in, U, b, s, out, N, C, K, 1, slabs, tickets, err, dbg, Geo{}};
+  for (int i = 0; i < 200; i++) hipLaunchKernelGGL((wino_f2_small_kernel<CT, false, true>), dim3(K / (16 * CT), nT16, S), dim3(256), 0, 0, prm);
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> st((size_t)blocks * S * 8);
   CK(hipMemcpy(st.data(), dbg, st.size() * 8, hipMemcpyDeviceToHost));
