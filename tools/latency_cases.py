@@ -87,6 +87,14 @@ def block(N, **kw):
 
 
 small = lambda ct, sp: dict(WINO_3X3_ALGO="small", WINO_SMALL_CT=ct, WINO_SMALL_SPLIT=sp)
+if mode == "s8":   # more workgroups than CUs at one image: two co-resident workgroups per CU, one round each
+    for C, N in ((256, 1), (256, 2), (512, 1), (384, 1)):
+        conv3(C, N)
+        for ct, sp in ((1, 4), (1, 8), (2, 8)):
+            conv3(C, N, **small(ct, sp))
+    for c in cases:
+        print(json.dumps(c), flush=True)
+    sys.exit(0)
 if mode == "stages":   # ResNet's four 3x3 stages at small batches: the latency kernel against the throughput kernel
     for HW, C in ((56, 64), (28, 128), (14, 256), (7, 512)):
         for N in (1, 2, 4, 8):
