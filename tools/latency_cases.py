@@ -95,6 +95,14 @@ if mode == "s8":   # more workgroups than CUs at one image: two co-resident work
     for c in cases:
         print(json.dumps(c), flush=True)
     sys.exit(0)
+if mode == "policy":   # the automatic choice against the forced throughput kernel over a grid of shapes the model was not fitted on
+    for C in (64, 128, 192, 256, 320, 384, 448, 512):
+        for N in (1, 3, 7, 13, 21, 33, 47):
+            conv3(C, N)
+            conv3(C, N, WINO_3X3_ALGO="big")
+    for c in cases:
+        print(json.dumps(c), flush=True)
+    sys.exit(0)
 if mode == "stages":   # ResNet's four 3x3 stages at small batches: the latency kernel against the throughput kernel
     for HW, C in ((56, 64), (28, 128), (14, 256), (7, 512)):
         for N in (1, 2, 4, 8):
