@@ -271,6 +271,78 @@ def test_one_by_one_latency_chained_forms(N, H, W, Cin, Kout, pkg, torch_dev, kn
     run("auto")
 
 
+def test_latency_kernels_random_shapes(pkg, torch_dev, knobs):
+    """Seeded sweep of the two latency kernels with their forms FORCED (the automatic choice would send most of these
+    shapes to the throughput kernels): random legal shapes -- 3x3: any N, H, W, C % 16, K % 64 (wider blocks where K
+    allows), a random split; 1x1: any M, Cin % 32, Kout % 64, random (K-split, row tiles, column tiles), random
+    chaining flags -- against the direct GPU comparators (no Winograd, no MFMA) on NaN-filled outputs."""
+    torch, dev = torch_dev
+    rng = np.random.RandomState(4242)
+    mk = lambda *s: torch.from_numpy(((rng.rand(*s) - 0.5) * 2).astype(np.float32)).to(dev)
+    knobs.set("WINO_3X3_ALGO", "small")
+    for i in range(24):
+        N = int(rng.randint(1, 5)); H = int(rng.randint(1, 19)); W = int(rng.randint(1, 19))
+        C = 16 * int(rng.randint(1, 13)); K = 64 * int(rng.randint(1, 4))
+        ct = int(rng.choice([1, 2, 4]))
+        smax = max(1, min(8, (C // 16) // 2))
+        sp = int(rng.randint(1, smax + 1))
+        knobs.set("WINO_SMALL_CT", ct)
+        knobs.set("WINO_SMALL_SPLIT", sp)
+        x, w, s, b = mk(N, H + 2, W + 2, C), mk(K, C, 3, 3), mk(K), mk(K)
+        U = pkg.filter_transform_f2(w)
+        assert pkg.small_plan_3x3_full(N, C, K, H=H, W=W)[:4] == (1, 2, sp, ct), (N, H, W, C, K, ct, sp)
+        out = torch.full((N, H + 2, W + 2, K), float("nan"), device=dev)
+        pkg.conv3x3_bn_relu(x, U, b, s, relu=bool(i & 1), out=out)
+        want = pkg.conv3x3_direct(x, w, b, s, relu=bool(i & 1))
+        assert not bool(torch.isnan(out).any()), (N, H, W, C, K, ct, sp)
+        inner = (slice(None), slice(1, H + 1), slice(1, W + 1), slice(None))
+        assert float((out[inner] - want[inner]).abs().max()) < TIGHT * float(want[inner].abs().max() + 1e-6), (N, H, W, C, K, ct, sp)
+        ring = torch.ones(H + 2, W + 2, dtype=torch.bool, device=dev)
+        ring[1:-1, 1:-1] = False
+        assert bool((out[:, ring, :] == 0).all()), (N, H, W, C, K, ct, sp)
+        assert pkg.tickets_in_use() == 0
+    for k in ("WINO_3X3_ALGO", "WINO_SMALL_CT", "WINO_SMALL_SPLIT"):
+        knobs.unset(k)
+    knobs.set("WINO_1X1_ALGO", "small")
+    done = 0
+    for i in range(60):
+        H = int(rng.randint(1, 15)); W = int(rng.randint(1, 15)); N = int(rng.randint(1, 4))
+        M = N * H * W
+        Cin = 32 * int(rng.randint(1, 17)); Kout = 64 * int(rng.randint(1, 9))
+        ks, rt, ct = int(rng.choice([1, 2, 4])), int(rng.choice([1, 2])), int(rng.choice([1, 2, 4]))
+        if Cin % (16 * ks) or Kout % ((4 // ks) * ct * 16) or (Cin // ks < 64 and ks > 1):
+            continue
+        knobs.set("WINO_1X1_SMALL_KS", ks)
+        knobs.set("WINO_1X1_SMALL_RT", rt)
+        knobs.set("WINO_1X1_SMALL_CT", ct)
+        flags = int(rng.choice([0, pkg.RELU])) | int(rng.choice([0, pkg.A_PADDED])) | int(rng.choice([0, pkg.C_PADDED])) | int(rng.choice([0, pkg.ADD_RESIDUAL]))
+        A, Bm, b, s, R = mk(N, H, W, Cin), mk(Cin, Kout), mk(Kout), mk(Kout), mk(M, Kout)
+        Ap = mk(N, H + 2, W + 2, Cin) * 50
+        Ap[:, 1:-1, 1:-1, :] = A
+        lin = pkg.conv1x1_direct(A.reshape(M, Cin), Bm, b, s, False)
+        if flags & pkg.ADD_RESIDUAL:
+            lin = lin + R
+        want = torch.relu(lin) if flags & pkg.RELU else lin
+        shape = (N, H + 2, W + 2, Kout) if flags & pkg.C_PADDED else (M, Kout)
+        out = torch.full(shape, float("nan"), device=dev)
+        pkg.conv1x1_bn_ex(Ap if flags & pkg.A_PADDED else A, Bm, b, s, flags, residual=R if flags & pkg.ADD_RESIDUAL else None,
+                          out=out, hw=(H, W))
+        tag = (M, Cin, Kout, ks, rt, ct, flags)
+        if flags & pkg.C_PADDED:
+            ring = torch.ones(H + 2, W + 2, dtype=torch.bool, device=dev)
+            ring[1:-1, 1:-1] = False
+            assert bool((out[:, ring, :] == 0).all()), tag
+            got = out[:, 1:-1, 1:-1, :].reshape(M, Kout)
+        else:
+            got = out
+        assert not bool(torch.isnan(got).any()), tag
+        assert float((got - want).abs().max()) < TIGHT * float(want.abs().max() + 1e-6), tag
+        done += 1
+    assert done >= 20
+    for k in ("WINO_1X1_ALGO", "WINO_1X1_SMALL_KS", "WINO_1X1_SMALL_RT", "WINO_1X1_SMALL_CT"):
+        knobs.unset(k)
+
+
 # ------------------------------------------------------------------ recovery after an aborted launch
 @pytest.mark.parametrize("kind", ["3x3 throughput", "3x3 latency", "3x3 latency wide", "1x1"])
 def test_a_dirty_ticket_counter_is_reported_and_reset_recovers(kind, pkg, torch_dev, knobs):
