@@ -43,7 +43,11 @@ xs = torch.rand(64, 16, 16, 128, device=dev); Us = pkg.filter_transform_f2(torch
 use_side = os.environ.get("SOAK_SIDE", "1") != "0"
 t0, launches, bad = time.time(), 0, 0
 stats = {}
+last_note = t0
 while time.time() - t0 < budget:
+    if time.time() - last_note > 60:   # (a GPU box takes seven silent minutes for a hang)
+        last_note = time.time()
+        print("soak: %d launches, %d differ, %.0f s" % (launches, bad, last_note - t0), flush=True)
     for c in cfgs_small:
         N, C, K, (sp, ct), x, U, b, s, ref = c
         os.environ.update(WINO_3X3_ALGO="small", WINO_SMALL_SPLIT=str(sp), WINO_SMALL_CT=str(ct))
